@@ -1,0 +1,403 @@
+"""Python host side over the C ABI (include/mi355_interp.h).
+
+PyTorch is plumbing only: device memory (torch.Tensor on cuda:N), streams and,
+in bench.py, torch.distributed.  Every computation runs in libmi355interp.so;
+nothing here has a CPU or eager-torch fallback.
+
+Names follow the reference's domain: grids / nodes / queries for the tables,
+realisations / spikes for EventDrivenMap (EventDrivenMap.hpp:11-121).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import EdmParams, MiError, check  # noqa: F401
+
+MI_GRID_SANITISE = 0x1
+MI_GRID_DEVICE_PTRS = 0x2
+MATH_EXACT = 0
+MATH_FAST = 1
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _ptr(t):
+    """Device/host address of a torch tensor or numpy array (must be contiguous)."""
+    if isinstance(t, np.ndarray):
+        assert t.flags["C_CONTIGUOUS"]
+        return C.c_void_p(t.ctypes.data)
+    assert t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def _np64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+
+
+class Context:
+    """mi_ctx: one device + one stream.  By default it follows torch's current stream."""
+
+    def __init__(self, device=0, stream="torch"):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        check(self._L.mi_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        if stream == "torch":
+            self.use_torch_stream()
+        elif stream is not None:
+            self.set_stream(stream)
+
+    def use_torch_stream(self):
+        torch = _torch()
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_stream(self, raw_stream):
+        check(self._L.mi_ctx_set_stream(self._h, C.c_void_p(raw_stream)), self._h)
+
+    def synchronize(self):
+        check(self._L.mi_ctx_synchronize(self._h), self._h)
+
+    def device_info(self):
+        name = C.create_string_buffer(128)
+        cus, hbm = C.c_int(0), C.c_size_t(0)
+        check(self._L.mi_ctx_device_info(self._h, name, 128, C.byref(cus), C.byref(hbm)), self._h)
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
+
+    def timer(self):
+        return Timer(self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mi_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Timer:
+    """HIP events recorded on the context's stream."""
+
+    def __init__(self, ctx):
+        self._ctx = ctx
+        self._L = ctx._L
+        h = C.c_void_p()
+        check(self._L.mi_timer_create(ctx._h, C.byref(h)), ctx._h)
+        self._h = h
+
+    def start(self):
+        check(self._L.mi_timer_start(self._h), self._ctx._h)
+
+    def stop(self):
+        check(self._L.mi_timer_stop(self._h), self._ctx._h)
+
+    def elapsed_ms(self):
+        ms = C.c_float(0)
+        check(self._L.mi_timer_elapsed_ms(self._h, C.byref(ms)), self._ctx._h)
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.mi_timer_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class Grid1:
+    """HBM-resident 1-D table (mi_grid1)."""
+
+    def __init__(self, ctx, handle):
+        self._ctx, self._h, self._L = ctx, handle, ctx._L
+
+    @classmethod
+    def from_nodes(cls, ctx, x, y, sanitise=True):
+        """Explicit abscissae -- the arma::interp1(X, Y, ...) table."""
+        x, y = _np64(x), _np64(y)
+        if x.size != y.size:
+            raise ValueError("X and Y must have the same number of elements")
+        h = C.c_void_p()
+        check(ctx._L.mi_grid1_create(ctx._h, _ptr(x), _ptr(y), x.size,
+                                     MI_GRID_SANITISE if sanitise else 0, C.byref(h)), ctx._h)
+        return cls(ctx, h)
+
+    @classmethod
+    def uniform(cls, ctx, x0, dx, y):
+        """Implicit grid X_i = fma(i, dx, x0)."""
+        y = _np64(y)
+        h = C.c_void_p()
+        check(ctx._L.mi_grid1_create_uniform(ctx._h, float(x0), float(dx), _ptr(y), y.size, 0, C.byref(h)), ctx._h)
+        return cls(ctx, h)
+
+    def info(self):
+        n, mode, tb = C.c_size_t(0), C.c_int(0), C.c_size_t(0)
+        check(self._L.mi_grid1_info(self._h, C.byref(n), C.byref(mode), C.byref(tb)), self._ctx._h)
+        return {"n_nodes": n.value, "mode": mode.value, "table_bytes": tb.value}
+
+    def interp(self, xq, out=None, extrap=math.nan):
+        """xq: float64 cuda tensor -> float64 cuda tensor (asynchronous on the ctx stream)."""
+        torch = _torch()
+        if not (xq.is_cuda and xq.dtype == torch.float64 and xq.is_contiguous()):
+            raise ValueError("xq must be a contiguous float64 CUDA tensor")
+        if out is None:
+            out = torch.empty_like(xq)
+        elif not (out.is_cuda and out.dtype == torch.float64 and out.is_contiguous() and out.numel() == xq.numel()):
+            raise ValueError("out must be a contiguous float64 CUDA tensor of the same size")
+        check(self._L.mi_interp1_f64_dev(self._ctx._h, self._h, _ptr(xq), _ptr(out), xq.numel(), float(extrap)),
+              self._ctx._h)
+        return out
+
+    def interp_host(self, xq, extrap=math.nan):
+        xq = _np64(xq)
+        out = np.empty_like(xq)
+        check(self._L.mi_interp1_f64_host(self._ctx._h, self._h, _ptr(xq), _ptr(out), xq.size, float(extrap)),
+              self._ctx._h)
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mi_grid1_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def interp1(ctx, X, Y, XI, extrap=math.nan):
+    """arma::interp1(X, Y, XI, YI, "linear", extrap) on host arrays, computed on the GPU."""
+    X, Y, XI = _np64(X), _np64(Y), _np64(XI)
+    if X.size != Y.size:
+        raise ValueError("X and Y must have the same number of elements")
+    YI = np.empty_like(XI)
+    check(ctx._L.mi_interp1_f64(ctx._h, _ptr(X), _ptr(Y), X.size, _ptr(XI), _ptr(YI), XI.size, float(extrap)), ctx._h)
+    return YI
+
+
+class Grid2:
+    """HBM-resident 2-D table (mi_grid2); z is (ny, nx), stored column-major like arma::mat."""
+
+    def __init__(self, ctx, handle):
+        self._ctx, self._h, self._L = ctx, handle, ctx._L
+
+    @staticmethod
+    def _colmajor(z, ny, nx):
+        z = np.asarray(z, dtype=np.float64)
+        if z.shape != (ny, nx):
+            raise ValueError("Z must have shape (len(y), len(x))")
+        return np.ascontiguousarray(z.T).reshape(-1)
+
+    @classmethod
+    def from_axes(cls, ctx, x, y, z):
+        x, y = _np64(x), _np64(y)
+        zc = cls._colmajor(z, y.size, x.size)
+        h = C.c_void_p()
+        check(ctx._L.mi_grid2_create(ctx._h, _ptr(x), x.size, _ptr(y), y.size, _ptr(zc), 0, C.byref(h)), ctx._h)
+        return cls(ctx, h)
+
+    @classmethod
+    def uniform(cls, ctx, x0, dx, nx, y0, dy, ny, z):
+        """z: (ny, nx) numpy array, or a column-major float64 CUDA tensor of ny*nx elements."""
+        h = C.c_void_p()
+        if isinstance(z, np.ndarray) or not hasattr(z, "is_cuda"):
+            zc = cls._colmajor(z, ny, nx)
+            flags = 0
+        else:
+            if z.numel() != nx * ny:
+                raise ValueError("Z must have nx*ny elements")
+            zc, flags = z, MI_GRID_DEVICE_PTRS
+        check(ctx._L.mi_grid2_create_uniform(ctx._h, float(x0), float(dx), nx, float(y0), float(dy), ny,
+                                             _ptr(zc), flags, C.byref(h)), ctx._h)
+        return cls(ctx, h)
+
+    def interp(self, xq, yq, out=None, extrap=math.nan):
+        torch = _torch()
+        for t in (xq, yq):
+            if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+                raise ValueError("queries must be contiguous float64 CUDA tensors")
+        if xq.numel() != yq.numel():
+            raise ValueError("xq and yq must have the same number of elements")
+        if out is None:
+            out = torch.empty_like(xq)
+        check(self._L.mi_interp2_f64_dev(self._ctx._h, self._h, _ptr(xq), _ptr(yq), _ptr(out), xq.numel(),
+                                         float(extrap)), self._ctx._h)
+        return out
+
+    def interp_host(self, xq, yq, extrap=math.nan):
+        xq, yq = _np64(xq), _np64(yq)
+        out = np.empty_like(xq)
+        check(self._L.mi_interp2_f64_host(self._ctx._h, self._h, _ptr(xq), _ptr(yq), _ptr(out), xq.size,
+                                          float(extrap)), self._ctx._h)
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mi_grid2_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- the reference's own step: Restrict + masked mean (EventDrivenMap.cu:769-824) ----
+
+def restrict(ctx, t0, i0, t1, i1, final_time, half_length, ngrid, out=None):
+    """RestrictKernel: CUDA tensors t0,t1 float32 and i0,i1 uint16 (or int16 views), [spike][realisation]."""
+    torch = _torch()
+    if out is None:
+        out = torch.empty_like(t0)
+    check(ctx._L.mi_restrict_f32_dev(ctx._h, _ptr(t0), _ptr(i0), _ptr(t1), _ptr(i1), float(final_time),
+                                     float(half_length), int(ngrid), _ptr(out), t0.numel()), ctx._h)
+    return out
+
+
+def masked_mean(ctx, x, accept, nspikes, quirk=False, want_sums=False):
+    torch = _torch()
+    nreal = accept.numel()
+    assert x.numel() == nspikes * nreal
+    mean = torch.empty(nspikes, dtype=torch.float32, device=x.device)
+    count = torch.empty(1, dtype=torch.int32, device=x.device)
+    sums = torch.empty(nspikes, dtype=torch.float64, device=x.device) if want_sums else None
+    check(ctx._L.mi_masked_mean_f32_dev(ctx._h, _ptr(x), _ptr(accept), nreal, nspikes, int(bool(quirk)),
+                                        _ptr(mean), _ptr(count), _ptr(sums) if want_sums else None), ctx._h)
+    return (mean, count, sums) if want_sums else (mean, count)
+
+
+def restrict_mean(ctx, t0, i0, t1, i1, accept, final_time, half_length, ngrid, nspikes, quirk=False,
+                  want_restricted=False, want_sums=False):
+    torch = _torch()
+    nreal = accept.numel()
+    assert t0.numel() == nspikes * nreal
+    mean = torch.empty(nspikes, dtype=torch.float32, device=t0.device)
+    count = torch.empty(1, dtype=torch.int32, device=t0.device)
+    sums = torch.empty(nspikes, dtype=torch.float64, device=t0.device) if want_sums else None
+    restricted = torch.empty_like(t0) if want_restricted else None
+    check(ctx._L.mi_restrict_mean_f32_dev(ctx._h, _ptr(t0), _ptr(i0), _ptr(t1), _ptr(i1), _ptr(accept),
+                                          float(final_time), float(half_length), int(ngrid), nreal, nspikes,
+                                          int(bool(quirk)), _ptr(restricted) if want_restricted else None,
+                                          _ptr(mean), _ptr(count), _ptr(sums) if want_sums else None), ctx._h)
+    return {"mean": mean, "count": count, "sums": sums, "restricted": restricted}
+
+
+# ---- EventDrivenMap (EventDrivenMap.hpp:11-121) ---------------------------------------
+
+def default_edm_params(**overrides):
+    p = EdmParams()
+    _lib.load().mi_edm_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError("mi_edm_params has no field %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+class EventDrivenMap:
+    """Mirror of the reference class: ComputeF(Z) -> f through lift/evolve/restrict/average."""
+
+    def __init__(self, ctx, parameters, noReal, **overrides):
+        self._ctx, self._L = ctx, ctx._L
+        par = np.atleast_1d(np.asarray(parameters, dtype=np.float64))
+        self.params = default_edm_params(beta_mean=float(np.float32(par[0])), n_real=int(noReal), **overrides)
+        h = C.c_void_p()
+        check(self._L.mi_edm_create(ctx._h, C.byref(self.params), C.byref(h)), ctx._h)
+        self._h = h
+
+    def _push(self):
+        check(self._L.mi_edm_set_params(self._h, C.byref(self.params)), self._ctx._h)
+
+    # setters of EventDrivenMap.hpp:27-51
+    def SetTimeHorizon(self, T):
+        assert T > 0
+        self.params.time_horizon = float(T)
+        self._push()
+
+    def SetNoRealisations(self, noReal):
+        assert noReal > 0
+        self.params.n_real = int(noReal)
+        self._push()
+
+    def SetNoThreads(self, noThreads):
+        assert 0 < noThreads <= 1024
+        self.params.n_grid = int(noThreads)
+        self._push()
+
+    def SetParameterStdDev(self, sigma):
+        assert sigma >= 0
+        self.params.beta_stddev = float(sigma)
+        self._push()
+
+    def SetParameters(self, parId, parVal):
+        assert parId == 0
+        self.params.beta_mean = float(parVal)
+        self._push()
+
+    def SetSeed(self, seed):
+        self.params.seed = int(seed)
+        self._push()
+
+    def PostProcess(self):
+        """EventDrivenMap.cu:343-346 draws a new seed; here: advance it deterministically."""
+        self.params.seed = (int(self.params.seed) * 6364136223846793005 + 1442695040888963407) & (2**64 - 1)
+        self._push()
+
+    def ComputeF(self, Z, want_partial=False):
+        Z = _np64(Z)
+        S = int(self.params.n_spikes)
+        if Z.size != S:
+            raise ValueError("Z must have n_spikes=%d elements" % S)
+        f = np.empty(S, dtype=np.float64)
+        partial = np.empty(S + 1, dtype=np.float64) if want_partial else None
+        check(self._L.mi_edm_compute_f(self._h, _ptr(Z), _ptr(f), _ptr(partial) if want_partial else None),
+              self._ctx._h)
+        return (f, partial) if want_partial else f
+
+    def residual_from_sums(self, Z, sums_and_count):
+        Z, sc = _np64(Z), _np64(sums_and_count)
+        f = np.empty(int(self.params.n_spikes), dtype=np.float64)
+        check(self._L.mi_edm_residual_from_sums(C.byref(self.params), _ptr(Z), _ptr(sc), _ptr(f)), self._ctx._h)
+        return f
+
+    def debug_read(self):
+        """Stage outputs of the last ComputeF (the reference's Save* taps, EventDrivenMap.cu:406-503)."""
+        S, R, N = int(self.params.n_spikes), int(self.params.n_real), int(self.params.n_grid)
+        out = {
+            "v": np.empty(N, np.float32), "s": np.empty(N, np.float32), "w": np.empty(N, np.float32),
+            "t0": np.empty(S * R, np.float32), "i0": np.empty(S * R, np.uint16),
+            "t1": np.empty(S * R, np.float32), "i1": np.empty(S * R, np.uint16),
+            "accept": np.empty(R, np.uint32), "restricted": np.empty(S * R, np.float32),
+            "seed_ind": np.empty(S, np.uint16),
+        }
+        order = ["v", "s", "w", "t0", "i0", "t1", "i1", "accept", "restricted", "seed_ind"]
+        check(self._L.mi_edm_debug_read(self._h, *[_ptr(out[k]) for k in order]), self._ctx._h)
+        return out
+
+    def last_timings(self):
+        ms = (C.c_float * 4)()
+        check(self._L.mi_edm_last_timings(self._h, C.byref(ms)), self._ctx._h)
+        return {"lift_ms": ms[0], "evolve_ms": ms[1], "restrict_mean_ms": ms[2], "total_ms": ms[3]}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mi_edm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

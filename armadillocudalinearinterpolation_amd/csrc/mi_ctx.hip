@@ -1,0 +1,162 @@
+// Context, error reporting and HIP-event timers of libmi355interp.so.
+#include "mi_common.hpp"
+
+namespace mi {
+
+char* tls_error()
+{
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+mi_status fail(const mi_ctx* ctx, mi_status code, const char* fmt, ...)
+{
+    char* dst = ctx ? ctx->err : tls_error();
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    if (ctx) {  // keep the thread-local copy in sync so mi_last_error(NULL) also works
+        strncpy(tls_error(), dst, 511);
+    }
+    return code;
+}
+
+mi_status ensure_scratch(mi_ctx* ctx, int slot, size_t bytes)
+{
+    if (ctx->scratch_bytes[slot] >= bytes) return MI_OK;
+    if (ctx->scratch[slot]) {
+        MI_HIP(ctx, hipFree(ctx->scratch[slot]));
+        ctx->scratch[slot] = nullptr;
+        ctx->scratch_bytes[slot] = 0;
+    }
+    size_t want = bytes + (bytes >> 2) + 4096;
+    hipError_t e = hipMalloc(&ctx->scratch[slot], want);
+    if (e != hipSuccess)
+        return fail(ctx, MI_ERR_NOMEM, "hipMalloc(%zu) for scratch failed: %s", want, hipGetErrorString(e));
+    ctx->scratch_bytes[slot] = want;
+    return MI_OK;
+}
+
+}  // namespace mi
+
+extern "C" {
+
+int mi_abi_version(void) { return MI355_INTERP_ABI_VERSION; }
+
+const char* mi_last_error(const mi_ctx* ctx) { return ctx ? ctx->err : mi::tls_error(); }
+
+mi_status mi_ctx_create(int device, mi_ctx** out)
+{
+    if (!out) return mi::fail(nullptr, MI_ERR_INVALID_ARG, "mi_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return mi::fail(nullptr, MI_ERR_NO_DEVICE,
+                        "mi_ctx_create: no HIP device available (%s); this library has no CPU fallback",
+                        e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= count)
+        return mi::fail(nullptr, MI_ERR_INVALID_ARG, "mi_ctx_create: device %d out of range [0,%d)", device, count);
+    MI_HIP(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MI_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+    mi_ctx* c = new (std::nothrow) mi_ctx();
+    if (!c) return mi::fail(nullptr, MI_ERR_NOMEM, "mi_ctx_create: out of host memory");
+    c->device = device;
+    c->compute_units = prop.multiProcessorCount;
+    c->hbm_bytes = prop.totalGlobalMem;
+    snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+    e = hipMalloc(&c->reduce_ws, mi_ctx::kReduceWsBytes);
+    if (e != hipSuccess) {
+        delete c;
+        return mi::fail(nullptr, MI_ERR_NOMEM, "mi_ctx_create: hipMalloc of the reduction workspace failed: %s",
+                        hipGetErrorString(e));
+    }
+    *out = c;
+    return MI_OK;
+}
+
+mi_status mi_ctx_destroy(mi_ctx* ctx)
+{
+    if (!ctx) return MI_OK;
+    hipSetDevice(ctx->device);
+    for (int i = 0; i < 3; ++i)
+        if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
+    if (ctx->reduce_ws) hipFree(ctx->reduce_ws);
+    delete ctx;
+    return MI_OK;
+}
+
+mi_status mi_ctx_set_stream(mi_ctx* ctx, void* stream)
+{
+    MI_REQUIRE(ctx, ctx != nullptr, "mi_ctx_set_stream: ctx is NULL");
+    ctx->stream = (hipStream_t)stream;
+    return MI_OK;
+}
+
+mi_status mi_ctx_synchronize(mi_ctx* ctx)
+{
+    MI_REQUIRE(ctx, ctx != nullptr, "mi_ctx_synchronize: ctx is NULL");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+
+mi_status mi_ctx_device_info(mi_ctx* ctx, char* name, size_t name_len, int* compute_units, size_t* hbm_bytes)
+{
+    MI_REQUIRE(ctx, ctx != nullptr, "mi_ctx_device_info: ctx is NULL");
+    if (name && name_len) {
+        strncpy(name, ctx->name, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (compute_units) *compute_units = ctx->compute_units;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return MI_OK;
+}
+
+mi_status mi_timer_create(mi_ctx* ctx, mi_timer** out)
+{
+    MI_REQUIRE(ctx, ctx && out, "mi_timer_create: NULL argument");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    mi_timer* t = new (std::nothrow) mi_timer();
+    if (!t) return mi::fail(ctx, MI_ERR_NOMEM, "mi_timer_create: out of host memory");
+    t->ctx = ctx;
+    MI_HIP(ctx, hipEventCreate(&t->start));
+    MI_HIP(ctx, hipEventCreate(&t->stop));
+    *out = t;
+    return MI_OK;
+}
+
+mi_status mi_timer_destroy(mi_timer* t)
+{
+    if (!t) return MI_OK;
+    hipEventDestroy(t->start);
+    hipEventDestroy(t->stop);
+    delete t;
+    return MI_OK;
+}
+
+mi_status mi_timer_start(mi_timer* t)
+{
+    MI_REQUIRE(nullptr, t != nullptr, "mi_timer_start: timer is NULL");
+    MI_HIP(t->ctx, hipEventRecord(t->start, t->ctx->stream));
+    return MI_OK;
+}
+
+mi_status mi_timer_stop(mi_timer* t)
+{
+    MI_REQUIRE(nullptr, t != nullptr, "mi_timer_stop: timer is NULL");
+    MI_HIP(t->ctx, hipEventRecord(t->stop, t->ctx->stream));
+    return MI_OK;
+}
+
+mi_status mi_timer_elapsed_ms(mi_timer* t, float* ms)
+{
+    MI_REQUIRE(nullptr, t && ms, "mi_timer_elapsed_ms: NULL argument");
+    MI_HIP(t->ctx, hipEventSynchronize(t->stop));
+    MI_HIP(t->ctx, hipEventElapsedTime(ms, t->start, t->stop));
+    return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,482 @@
+// 1-D table interpolation on MI355X (gfx950): HBM-resident tables + the
+// streaming gather-and-blend kernels.  Hand-written HIP; bandwidth-bound
+// (8 B in + 8 B out per query), no MFMA.
+//
+// Semantics: include/mi355_interp.h ("fp64 blend") == oracle/interp_oracle.c.
+// The file is compiled with -ffp-contract=off so that every product and sum of
+// the blend rounds separately, exactly like the oracle.
+//
+// Table layouts (all with one padding node so that node l+1 is always
+// readable):
+//   mode 0  implicit uniform   y[n+1]                 8 B/node, X_i = fma(i,dx,x0)
+//   mode 1  explicit + guess   {x,y}[n+1]            16 B/node, one 32-B gather/query
+//   mode 2  explicit + buckets {x,y}[n+1] + u32[nb+1] bucket index, then a
+//           binary search confined to the bucket's node range
+// Mode 1 is chosen when the analytic guess g(q) = (q-xmin)*(n-1)/(xmax-xmin)
+// provably lands within a few nodes of the bracket for every possible query
+// (verified against every node at build time); otherwise mode 2.
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "mi_common.hpp"
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+struct G1Dev {
+    const d2* nodes;     // modes 1, 2
+    const double* y;     // mode 0
+    const uint32_t* s;   // mode 2
+    int n;               // nodes
+    int nb;              // buckets (mode 2)
+    double xmin, xmax;
+    double scale;        // mode 0: 1/dx; mode 1: (n-1)/(xmax-xmin); mode 2: nb/(xmax-xmin)
+    double x0, dx;       // mode 0
+};
+
+struct mi_grid1 {
+    mi_ctx* ctx;
+    int mode;
+    size_t n;
+    size_t table_bytes;
+    void* dev_nodes;     // d2[n+1] or double[n+1]
+    void* dev_s;         // u32[nb+1] or null
+    G1Dev d;
+};
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxWalk = 4;   // widest guess window for which mode 1 is used
+
+struct __attribute__((packed, aligned(8))) ypair {
+    double a, b;
+};
+
+__device__ __forceinline__ double blend(double xa, double ya, double xb, double yb, double q)
+{
+    const double a = q - xa;
+    const double b = xb - q;
+    const double w = (a > 0.0) ? a / (a + b) : 0.0;
+    return (1.0 - w) * ya + w * yb;
+}
+
+__device__ __forceinline__ double unode(const G1Dev& g, int i) { return fma((double)i, g.dx, g.x0); }
+
+// NQ independent queries per lane: all guesses first, then all gathers (so the
+// loads of the NQ queries are in flight together), then the rare fix-up walks
+// and the blend.
+template <int MODE, int NQ>
+__device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ], double (&out)[NQ],
+                                           double extrap)
+{
+    double qs[NQ];
+    int l[NQ];
+    bool oor[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        oor[k] = !(q[k] >= g.xmin && q[k] <= g.xmax);   // true for NaN as well
+        qs[k] = oor[k] ? g.xmin : q[k];
+    }
+    if constexpr (MODE == 0) {
+        ypair yp[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            int i = (int)((qs[k] - g.x0) * g.scale);
+            i = min(max(i, 0), g.n - 1);
+            while (i > 0 && unode(g, i) > qs[k]) --i;
+            while (i < g.n - 1 && unode(g, i + 1) <= qs[k]) ++i;
+            l[k] = i;
+        }
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) yp[k] = *reinterpret_cast<const ypair*>(g.y + l[k]);
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int r = min(l[k] + 1, g.n - 1);
+            out[k] = blend(unode(g, l[k]), yp[k].a, unode(g, r), yp[k].b, qs[k]);
+        }
+    } else {
+        d2 n0[NQ], n1[NQ];
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                int i = (int)((qs[k] - g.xmin) * g.scale);
+                l[k] = min(max(i, 0), g.n - 2);
+            }
+        } else {
+            uint32_t lo[NQ], hi[NQ];
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                int b = (int)((qs[k] - g.xmin) * g.scale);
+                b = min(max(b, 0), g.nb - 1);
+                lo[k] = g.s[b];
+                hi[k] = g.s[b + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                uint32_t a = lo[k], c = hi[k];       // bracket index is in [a, c]
+                while (c > a) {
+                    const uint32_t mid = (a + c + 1u) >> 1;
+                    if (g.nodes[mid].x <= qs[k]) a = mid; else c = mid - 1u;
+                }
+                l[k] = (int)a;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            n0[k] = g.nodes[l[k]];
+            n1[k] = g.nodes[l[k] + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            if constexpr (MODE == 1) {
+                int i = l[k];
+                while (qs[k] < n0[k].x && i > 0) { --i; n1[k] = n0[k]; n0[k] = g.nodes[i]; }
+                while (qs[k] >= n1[k].x && i < g.n - 1) { ++i; n0[k] = n1[k]; n1[k] = g.nodes[i + 1]; }
+            }
+            out[k] = blend(n0[k].x, n0[k].y, n1[k].x, n1[k].y, qs[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        if (oor[k]) out[k] = (q[k] != q[k]) ? __builtin_nan("") : extrap;
+    }
+}
+
+// Vector kernel: each lane streams 16 B (two queries) per step with
+// non-temporal loads/stores (the streams must not evict the table from L2),
+// UNROLL steps per iteration.  Requires xq and yq 16-B aligned.
+template <int MODE, int UNROLL>
+__global__ __launch_bounds__(kBlock) void interp1_vec_kernel(G1Dev g, const double* __restrict__ xq,
+                                                             double* __restrict__ yq, size_t nq,
+                                                             double extrap)
+{
+    const size_t nvec = nq >> 1;
+    const d2* __restrict__ xv = reinterpret_cast<const d2*>(xq);
+    d2* __restrict__ yv = reinterpret_cast<d2*>(yq);
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    // full UNROLL-wide steps
+    for (; i + (size_t)(UNROLL - 1) * stride < nvec; i += (size_t)UNROLL * stride) {
+        double q[2 * UNROLL], r[2 * UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const d2 v = __builtin_nontemporal_load(xv + i + (size_t)u * stride);
+            q[2 * u] = v.x;
+            q[2 * u + 1] = v.y;
+        }
+        eval_batch<MODE, 2 * UNROLL>(g, q, r, extrap);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            d2 v;
+            v.x = r[2 * u];
+            v.y = r[2 * u + 1];
+            __builtin_nontemporal_store(v, yv + i + (size_t)u * stride);
+        }
+    }
+    for (; i < nvec; i += stride) {
+        const d2 v = __builtin_nontemporal_load(xv + i);
+        double q[2] = {v.x, v.y}, r[2];
+        eval_batch<MODE, 2>(g, q, r, extrap);
+        d2 o;
+        o.x = r[0];
+        o.y = r[1];
+        __builtin_nontemporal_store(o, yv + i);
+    }
+    if ((nq & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double q[1] = {xq[nq - 1]}, r[1];
+        eval_batch<MODE, 1>(g, q, r, extrap);
+        yq[nq - 1] = r[0];
+    }
+}
+
+// Scalar kernel for unaligned query/result pointers.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void interp1_scalar_kernel(G1Dev g, const double* __restrict__ xq,
+                                                                double* __restrict__ yq, size_t nq,
+                                                                double extrap)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nq; i += stride) {
+        double q[1] = {xq[i]}, r[1];
+        eval_batch<MODE, 1>(g, q, r, extrap);
+        yq[i] = r[0];
+    }
+}
+
+template <int MODE>
+mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, const double* xq, double* yq, size_t nq, double extrap)
+{
+    const bool aligned = ((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq)) & 15u) == 0;
+    if (aligned) {
+        constexpr int UNROLL = 2;
+        const unsigned grid = mi::stream_grid(ctx, (nq / 2 + UNROLL - 1) / UNROLL, kBlock);
+        hipLaunchKernelGGL((interp1_vec_kernel<MODE, UNROLL>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, xq,
+                           yq, nq, extrap);
+    } else {
+        const unsigned grid = mi::stream_grid(ctx, nq, kBlock);
+        hipLaunchKernelGGL((interp1_scalar_kernel<MODE>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, xq, yq,
+                           nq, extrap);
+    }
+    MI_LAUNCH_CHECK(ctx, "interp1 kernel");
+    return MI_OK;
+}
+
+// ---- host-side table construction -----------------------------------------
+
+inline int guess_index(double q, double xmin, double scale) { return (int)((q - xmin) * scale); }
+
+mi_status upload(mi_ctx* ctx, void** dev, const void* host, size_t bytes)
+{
+    hipError_t e = hipMalloc(dev, bytes);
+    if (e != hipSuccess) return mi::fail(ctx, MI_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    MI_HIP(ctx, hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+    return MI_OK;
+}
+
+// xs strictly increasing, finite, n >= 2
+mi_status build_explicit(mi_ctx* ctx, const std::vector<double>& xs, const std::vector<double>& ys, mi_grid1** out)
+{
+    const size_t n = xs.size();
+    if (n > 0x7ffffff0u) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_grid1_create: n=%zu exceeds 2^31", n);
+    mi_grid1* g = new (std::nothrow) mi_grid1();
+    if (!g) return mi::fail(ctx, MI_ERR_NOMEM, "mi_grid1_create: out of host memory");
+    g->ctx = ctx;
+    g->n = n;
+    g->dev_nodes = g->dev_s = nullptr;
+    std::vector<d2> nodes(n + 1);
+    for (size_t i = 0; i < n; ++i) {
+        nodes[i].x = xs[i];
+        nodes[i].y = ys[i];
+    }
+    nodes[n] = nodes[n - 1];   // padding node: r = min(l+1, n-1)
+    G1Dev& d = g->d;
+    memset(&d, 0, sizeof(d));
+    d.n = (int)n;
+    d.xmin = xs[0];
+    d.xmax = xs[n - 1];
+    const double span = d.xmax - d.xmin;
+
+    // Mode-1 test.  g(.) is monotone, so for a query q with bracket i
+    // (X[i] <= q < X[i+1]):  g(X[i]) <= g(q) <= g(X[i+1]).  With
+    // e_i = g(X[i]) - i in [e_lo, e_hi] for every node, the bracket lies in
+    // [g(q) - 1 - e_hi, g(q) - e_lo]: at most e_hi - e_lo + 1 walk steps.
+    const double scale1 = (double)(n - 1) / span;
+    long e_lo = 0, e_hi = 0;
+    bool finite_scale = std::isfinite(scale1) && scale1 > 0.0;
+    if (finite_scale) {
+        for (size_t i = 0; i < n; ++i) {
+            const double t = (xs[i] - d.xmin) * scale1;
+            long gi = (t >= 2147483000.0) ? 2147483000L : (long)(int)t;
+            gi = std::min<long>(std::max<long>(gi, 0), (long)n - 2);
+            const long e = gi - (long)i;
+            e_lo = std::min(e_lo, e);
+            e_hi = std::max(e_hi, e);
+        }
+    }
+    // the clamp to n-2 makes e = -1 at the last node; harmless (walk-up handles it)
+    if (finite_scale && (e_hi - e_lo + 1) <= kMaxWalk) {
+        g->mode = 1;
+        d.scale = scale1;
+    } else {
+        g->mode = 2;
+        size_t nb = n;
+        double bscale = (double)nb / span;
+        if (!std::isfinite(bscale) || !(bscale > 0.0)) {   // span underflow/overflow: one bucket
+            nb = 1;
+            bscale = 0.0;
+        }
+        d.nb = (int)nb;
+        d.scale = bscale;
+        // s[b] = largest node whose bucket is < b (0 if none); s[nb] = n-1
+        std::vector<uint32_t> s(nb + 1, 0);
+        auto bucket = [&](double x) {
+            const double t = (x - d.xmin) * bscale;
+            long b = (t >= 2147483000.0) ? 2147483000L : (long)(int)t;
+            return (size_t)std::min<long>(std::max<long>(b, 0), (long)nb - 1);
+        };
+        size_t bprev = bucket(xs[0]);   // == 0
+        for (size_t i = 1; i < n; ++i) {
+            const size_t bi = bucket(xs[i]);
+            for (size_t b = bprev + 1; b <= bi; ++b) s[b] = (uint32_t)(i - 1);
+            bprev = bi;
+        }
+        for (size_t b = bprev + 1; b <= nb; ++b) s[b] = (uint32_t)(n - 1);
+        mi_status st = upload(ctx, &g->dev_s, s.data(), (nb + 1) * sizeof(uint32_t));
+        if (st != MI_OK) { delete g; return st; }
+        d.s = (const uint32_t*)g->dev_s;
+    }
+    mi_status st = upload(ctx, &g->dev_nodes, nodes.data(), (n + 1) * sizeof(d2));
+    if (st != MI_OK) {
+        if (g->dev_s) hipFree(g->dev_s);
+        delete g;
+        return st;
+    }
+    d.nodes = (const d2*)g->dev_nodes;
+    g->table_bytes = (n + 1) * sizeof(d2) + (g->mode == 2 ? ((size_t)d.nb + 1) * 4 : 0);
+    *out = g;
+    return MI_OK;
+}
+
+mi_status fetch(mi_ctx* ctx, const double* p, size_t n, bool dev, std::vector<double>& v)
+{
+    v.resize(n);
+    if (dev) {
+        MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MI_HIP(ctx, hipMemcpy(v.data(), p, n * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+        memcpy(v.data(), p, n * sizeof(double));
+    }
+    return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+mi_status mi_grid1_create(mi_ctx* ctx, const double* x, const double* y, size_t n, unsigned flags, mi_grid1** out)
+{
+    MI_REQUIRE(ctx, ctx && x && y && out, "mi_grid1_create: NULL argument");
+    MI_REQUIRE(ctx, (flags & ~(MI_GRID_SANITISE | MI_GRID_DEVICE_PTRS)) == 0, "mi_grid1_create: unknown flags 0x%x", flags);
+    *out = nullptr;
+    if (n < 2) return mi::fail(ctx, MI_ERR_GRID, "mi_grid1_create: X must have at least two elements (n=%zu)", n);
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<double> xs, ys;
+    mi_status st = fetch(ctx, x, n, flags & MI_GRID_DEVICE_PTRS, xs);
+    if (st != MI_OK) return st;
+    st = fetch(ctx, y, n, flags & MI_GRID_DEVICE_PTRS, ys);
+    if (st != MI_OK) return st;
+    for (size_t i = 0; i < n; ++i)
+        if (!std::isfinite(xs[i]))
+            return mi::fail(ctx, MI_ERR_GRID, "mi_grid1_create: X[%zu] is not finite", i);
+    if (flags & MI_GRID_SANITISE) {
+        // arma::interp1 front end: unique + ascending sort of X, Y permuted
+        // alike (first occurrence of a duplicate abscissa is kept).
+        std::vector<size_t> idx(n);
+        for (size_t i = 0; i < n; ++i) idx[i] = i;
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return xs[a] < xs[b]; });
+        std::vector<double> x2, y2;
+        x2.reserve(n);
+        y2.reserve(n);
+        for (size_t k = 0; k < n; ++k) {
+            if (!x2.empty() && xs[idx[k]] == x2.back()) continue;
+            x2.push_back(xs[idx[k]]);
+            y2.push_back(ys[idx[k]]);
+        }
+        xs.swap(x2);
+        ys.swap(y2);
+        if (xs.size() < 2)
+            return mi::fail(ctx, MI_ERR_GRID, "mi_grid1_create: X must have at least two unique elements");
+    } else {
+        for (size_t i = 1; i < n; ++i)
+            if (!(xs[i - 1] < xs[i]))
+                return mi::fail(ctx, MI_ERR_GRID,
+                                "mi_grid1_create: X not strictly increasing at %zu (pass MI_GRID_SANITISE)", i);
+    }
+    return build_explicit(ctx, xs, ys, out);
+}
+
+mi_status mi_grid1_create_uniform(mi_ctx* ctx, double x0, double dx, const double* y, size_t n, unsigned flags,
+                                  mi_grid1** out)
+{
+    MI_REQUIRE(ctx, ctx && y && out, "mi_grid1_create_uniform: NULL argument");
+    MI_REQUIRE(ctx, (flags & ~MI_GRID_DEVICE_PTRS) == 0, "mi_grid1_create_uniform: unknown flags 0x%x", flags);
+    *out = nullptr;
+    if (n < 2) return mi::fail(ctx, MI_ERR_GRID, "mi_grid1_create_uniform: need at least two nodes (n=%zu)", n);
+    if (n > 0x7ffffff0u) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_grid1_create_uniform: n=%zu exceeds 2^31", n);
+    if (!(dx > 0.0) || !std::isfinite(dx) || !std::isfinite(x0) || !std::isfinite(std::fma((double)(n - 1), dx, x0)))
+        return mi::fail(ctx, MI_ERR_GRID, "mi_grid1_create_uniform: need finite x0 and dx > 0");
+    if (!(std::fma(1.0, dx, x0) > x0))
+        return mi::fail(ctx, MI_ERR_GRID, "mi_grid1_create_uniform: dx too small relative to x0");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<double> ys;
+    mi_status st = fetch(ctx, y, n, flags & MI_GRID_DEVICE_PTRS, ys);
+    if (st != MI_OK) return st;
+    ys.push_back(ys[n - 1]);
+    mi_grid1* g = new (std::nothrow) mi_grid1();
+    if (!g) return mi::fail(ctx, MI_ERR_NOMEM, "mi_grid1_create_uniform: out of host memory");
+    g->ctx = ctx;
+    g->mode = 0;
+    g->n = n;
+    g->dev_s = nullptr;
+    st = upload(ctx, &g->dev_nodes, ys.data(), (n + 1) * sizeof(double));
+    if (st != MI_OK) { delete g; return st; }
+    G1Dev& d = g->d;
+    memset(&d, 0, sizeof(d));
+    d.y = (const double*)g->dev_nodes;
+    d.n = (int)n;
+    d.x0 = x0;
+    d.dx = dx;
+    d.xmin = x0;
+    d.xmax = std::fma((double)(n - 1), dx, x0);
+    d.scale = 1.0 / dx;
+    g->table_bytes = (n + 1) * sizeof(double);
+    *out = g;
+    return MI_OK;
+}
+
+mi_status mi_grid1_destroy(mi_grid1* g)
+{
+    if (!g) return MI_OK;
+    hipSetDevice(g->ctx->device);
+    if (g->dev_nodes) hipFree(g->dev_nodes);
+    if (g->dev_s) hipFree(g->dev_s);
+    delete g;
+    return MI_OK;
+}
+
+mi_status mi_grid1_info(const mi_grid1* g, size_t* n_nodes, int* mode, size_t* table_bytes)
+{
+    MI_REQUIRE(nullptr, g != nullptr, "mi_grid1_info: grid is NULL");
+    if (n_nodes) *n_nodes = g->n;
+    if (mode) *mode = g->mode;
+    if (table_bytes) *table_bytes = g->table_bytes;
+    return MI_OK;
+}
+
+mi_status mi_interp1_f64_dev(mi_ctx* ctx, const mi_grid1* g, const double* xq, double* yq, size_t nq, double extrap)
+{
+    MI_REQUIRE(ctx, ctx && g, "mi_interp1_f64_dev: NULL context or grid");
+    if (nq == 0) return MI_OK;
+    MI_REQUIRE(ctx, xq && yq, "mi_interp1_f64_dev: NULL query/result pointer");
+    MI_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq)) & 7u) == 0,
+               "mi_interp1_f64_dev: pointers must be 8-byte aligned");
+    switch (g->mode) {
+        case 0: return launch_mode<0>(ctx, g->d, xq, yq, nq, extrap);
+        case 1: return launch_mode<1>(ctx, g->d, xq, yq, nq, extrap);
+        default: return launch_mode<2>(ctx, g->d, xq, yq, nq, extrap);
+    }
+}
+
+mi_status mi_interp1_f64_host(mi_ctx* ctx, const mi_grid1* g, const double* xq, double* yq, size_t nq, double extrap)
+{
+    MI_REQUIRE(ctx, ctx && g, "mi_interp1_f64_host: NULL context or grid");
+    if (nq == 0) return MI_OK;
+    MI_REQUIRE(ctx, xq && yq, "mi_interp1_f64_host: NULL query/result pointer");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = nq * sizeof(double);
+    mi_status st = mi::ensure_scratch(ctx, 0, bytes);
+    if (st != MI_OK) return st;
+    st = mi::ensure_scratch(ctx, 1, bytes);
+    if (st != MI_OK) return st;
+    MI_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], xq, bytes, hipMemcpyHostToDevice, ctx->stream));
+    st = mi_interp1_f64_dev(ctx, g, (const double*)ctx->scratch[0], (double*)ctx->scratch[1], nq, extrap);
+    if (st != MI_OK) return st;
+    MI_HIP(ctx, hipMemcpyAsync(yq, ctx->scratch[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+
+mi_status mi_interp1_f64(mi_ctx* ctx, const double* x, const double* y, size_t n, const double* xq, double* yq,
+                         size_t nq, double extrap)
+{
+    mi_grid1* g = nullptr;
+    mi_status st = mi_grid1_create(ctx, x, y, n, MI_GRID_SANITISE, &g);
+    if (st != MI_OK) return st;
+    st = mi_interp1_f64_host(ctx, g, xq, yq, nq, extrap);
+    mi_grid1_destroy(g);
+    return st;
+}
+
+}  // extern "C"

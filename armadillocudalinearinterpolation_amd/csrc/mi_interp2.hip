@@ -1,0 +1,298 @@
+// Scattered bilinear interpolation over an HBM-resident column-major table
+// (arma::mat layout) on MI355X.  Semantics: oracle/interp_oracle.c
+// orc_interp2_bilinear[_uniform]; blend along y (contiguous) inside the two
+// bracketing columns, then along x.  16 B in + 8 B out per query; the table is
+// gathered through L2 / Infinity Cache as two 16-B {Z(l,c), Z(l+1,c)} pairs.
+// Compiled with -ffp-contract=off (every product/sum rounds separately).
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "mi_common.hpp"
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+struct AxisDev {
+    const double* nodes;   // explicit axis (null when implicit)
+    int n;
+    int use_guess;         // explicit: analytic guess + walk (1) or binary search (0)
+    double xmin, xmax, scale;
+    double x0, dx;         // implicit: node_i = fma(i, dx, x0)
+};
+
+struct G2Dev {
+    AxisDev ax, ay;
+    const double* z;       // ny*nx + 1 doubles, column-major
+};
+
+struct mi_grid2 {
+    mi_ctx* ctx;
+    void* dev_x;
+    void* dev_y;
+    void* dev_z;
+    G2Dev d;
+};
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxWalk = 4;
+
+struct __attribute__((packed, aligned(8))) zpair {
+    double a, b;
+};
+
+__device__ __forceinline__ double axis_node(const AxisDev& a, int i)
+{
+    return a.nodes ? a.nodes[i] : fma((double)i, a.dx, a.x0);
+}
+
+// largest l with node_l <= q (q inside [xmin, xmax])
+__device__ __forceinline__ int axis_locate(const AxisDev& a, double q)
+{
+    if (a.nodes && !a.use_guess) {
+        int lo = 0, hi = a.n;
+        while (hi - lo > 1) {
+            const int mid = lo + ((hi - lo) >> 1);
+            if (a.nodes[mid] <= q) lo = mid; else hi = mid;
+        }
+        return lo;
+    }
+    int i = (int)((q - a.xmin) * a.scale);
+    i = min(max(i, 0), a.n - 1);
+    while (i > 0 && axis_node(a, i) > q) --i;
+    while (i < a.n - 1 && axis_node(a, i + 1) <= q) ++i;
+    return i;
+}
+
+__device__ __forceinline__ double weight(double xa, double xb, double q)
+{
+    const double a = q - xa, b = xb - q;
+    return (a > 0.0) ? a / (a + b) : 0.0;
+}
+
+__device__ __forceinline__ double eval2(const G2Dev& g, double qx, double qy, double extrap)
+{
+    const bool oor = !(qx >= g.ax.xmin && qx <= g.ax.xmax && qy >= g.ay.xmin && qy <= g.ay.xmax);
+    const double sx = oor ? g.ax.xmin : qx, sy = oor ? g.ay.xmin : qy;
+    const int lx = axis_locate(g.ax, sx), ly = axis_locate(g.ay, sy);
+    const int rx = min(lx + 1, g.ax.n - 1), ry = min(ly + 1, g.ay.n - 1);
+    const size_t ny = (size_t)g.ay.n;
+    const zpair c0p = *reinterpret_cast<const zpair*>(g.z + (size_t)lx * ny + ly);
+    const zpair c1p = *reinterpret_cast<const zpair*>(g.z + (size_t)rx * ny + ly);
+    const double wx = weight(axis_node(g.ax, lx), axis_node(g.ax, rx), sx);
+    const double wy = weight(axis_node(g.ay, ly), axis_node(g.ay, ry), sy);
+    const double z01 = (ry != ly) ? c0p.b : c0p.a;
+    const double z11 = (ry != ly) ? c1p.b : c1p.a;
+    const double c0 = (1.0 - wy) * c0p.a + wy * z01;
+    const double c1 = (1.0 - wy) * c1p.a + wy * z11;
+    const double r = (1.0 - wx) * c0 + wx * c1;
+    if (oor) return (qx != qx || qy != qy) ? __builtin_nan("") : extrap;
+    return r;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void interp2_kernel(G2Dev g, const double* __restrict__ xq,
+                                                         const double* __restrict__ yq, double* __restrict__ zq,
+                                                         size_t nq, double extrap)
+{
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    if constexpr (VEC) {
+        const size_t nvec = nq >> 1;
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+            const d2 vx = __builtin_nontemporal_load(reinterpret_cast<const d2*>(xq) + i);
+            const d2 vy = __builtin_nontemporal_load(reinterpret_cast<const d2*>(yq) + i);
+            d2 o;
+            o.x = eval2(g, vx.x, vy.x, extrap);
+            o.y = eval2(g, vx.y, vy.y, extrap);
+            __builtin_nontemporal_store(o, reinterpret_cast<d2*>(zq) + i);
+        }
+        if ((nq & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+            zq[nq - 1] = eval2(g, xq[nq - 1], yq[nq - 1], extrap);
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nq; i += stride)
+            zq[i] = eval2(g, xq[i], yq[i], extrap);
+    }
+}
+
+mi_status to_host(mi_ctx* ctx, const double* p, size_t n, bool dev, std::vector<double>& v)
+{
+    v.resize(n);
+    if (dev) {
+        MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MI_HIP(ctx, hipMemcpy(v.data(), p, n * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+        memcpy(v.data(), p, n * sizeof(double));
+    }
+    return MI_OK;
+}
+
+mi_status make_explicit_axis(mi_ctx* ctx, const std::vector<double>& xs, const char* name, void** dev, AxisDev* a)
+{
+    const size_t n = xs.size();
+    for (size_t i = 0; i < n; ++i)
+        if (!std::isfinite(xs[i])) return mi::fail(ctx, MI_ERR_GRID, "mi_grid2_create: %s[%zu] is not finite", name, i);
+    for (size_t i = 1; i < n; ++i)
+        if (!(xs[i - 1] < xs[i]))
+            return mi::fail(ctx, MI_ERR_GRID, "mi_grid2_create: %s not strictly increasing at %zu", name, i);
+    memset(a, 0, sizeof(*a));
+    a->n = (int)n;
+    a->xmin = xs[0];
+    a->xmax = xs[n - 1];
+    const double scale = (double)(n - 1) / (a->xmax - a->xmin);
+    long e_lo = 0, e_hi = 0;
+    const bool ok = std::isfinite(scale) && scale > 0.0;
+    if (ok) {
+        for (size_t i = 0; i < n; ++i) {
+            long gi = (long)(int)((xs[i] - a->xmin) * scale);
+            gi = std::min<long>(std::max<long>(gi, 0), (long)n - 1);
+            e_lo = std::min(e_lo, gi - (long)i);
+            e_hi = std::max(e_hi, gi - (long)i);
+        }
+    }
+    a->use_guess = ok && (e_hi - e_lo + 1) <= kMaxWalk;
+    a->scale = ok ? scale : 0.0;
+    hipError_t e = hipMalloc(dev, n * sizeof(double));
+    if (e != hipSuccess) return mi::fail(ctx, MI_ERR_NOMEM, "hipMalloc axis failed: %s", hipGetErrorString(e));
+    MI_HIP(ctx, hipMemcpy(*dev, xs.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    a->nodes = (const double*)*dev;
+    return MI_OK;
+}
+
+mi_status make_uniform_axis(mi_ctx* ctx, double x0, double dx, size_t n, const char* name, AxisDev* a)
+{
+    if (!(dx > 0.0) || !std::isfinite(dx) || !std::isfinite(x0) || !std::isfinite(std::fma((double)(n - 1), dx, x0)) ||
+        !(std::fma(1.0, dx, x0) > x0))
+        return mi::fail(ctx, MI_ERR_GRID, "mi_grid2_create_uniform: bad %s axis (need finite origin, step > 0)", name);
+    memset(a, 0, sizeof(*a));
+    a->n = (int)n;
+    a->x0 = x0;
+    a->dx = dx;
+    a->xmin = x0;
+    a->xmax = std::fma((double)(n - 1), dx, x0);
+    a->scale = 1.0 / dx;
+    return MI_OK;
+}
+
+mi_status upload_z(mi_ctx* ctx, const double* z, size_t count, bool dev, void** out)
+{
+    hipError_t e = hipMalloc(out, (count + 1) * sizeof(double));
+    if (e != hipSuccess)
+        return mi::fail(ctx, MI_ERR_NOMEM, "hipMalloc(%zu) for Z failed: %s", (count + 1) * sizeof(double), hipGetErrorString(e));
+    MI_HIP(ctx, hipMemcpy(*out, z, count * sizeof(double), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    MI_HIP(ctx, hipMemset((char*)*out + count * sizeof(double), 0, sizeof(double)));
+    return MI_OK;
+}
+
+void destroy(mi_grid2* g)
+{
+    if (!g) return;
+    if (g->dev_x) hipFree(g->dev_x);
+    if (g->dev_y) hipFree(g->dev_y);
+    if (g->dev_z) hipFree(g->dev_z);
+    delete g;
+}
+
+}  // namespace
+
+extern "C" {
+
+mi_status mi_grid2_create(mi_ctx* ctx, const double* x, size_t nx, const double* y, size_t ny, const double* z,
+                          unsigned flags, mi_grid2** out)
+{
+    MI_REQUIRE(ctx, ctx && x && y && z && out, "mi_grid2_create: NULL argument");
+    MI_REQUIRE(ctx, (flags & ~MI_GRID_DEVICE_PTRS) == 0, "mi_grid2_create: unknown flags 0x%x", flags);
+    *out = nullptr;
+    if (nx < 2 || ny < 2) return mi::fail(ctx, MI_ERR_GRID, "mi_grid2_create: need at least 2x2 nodes");
+    MI_REQUIRE(ctx, nx < 0x7ffffff0u && ny < 0x7ffffff0u, "mi_grid2_create: axis too long");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    const bool dev = flags & MI_GRID_DEVICE_PTRS;
+    std::vector<double> xs, ys;
+    mi_status st = to_host(ctx, x, nx, dev, xs);
+    if (st != MI_OK) return st;
+    st = to_host(ctx, y, ny, dev, ys);
+    if (st != MI_OK) return st;
+    mi_grid2* g = new (std::nothrow) mi_grid2();
+    if (!g) return mi::fail(ctx, MI_ERR_NOMEM, "mi_grid2_create: out of host memory");
+    g->ctx = ctx;
+    g->dev_x = g->dev_y = g->dev_z = nullptr;
+    st = make_explicit_axis(ctx, xs, "X", &g->dev_x, &g->d.ax);
+    if (st == MI_OK) st = make_explicit_axis(ctx, ys, "Y", &g->dev_y, &g->d.ay);
+    if (st == MI_OK) st = upload_z(ctx, z, nx * ny, dev, &g->dev_z);
+    if (st != MI_OK) { destroy(g); return st; }
+    g->d.z = (const double*)g->dev_z;
+    *out = g;
+    return MI_OK;
+}
+
+mi_status mi_grid2_create_uniform(mi_ctx* ctx, double x0, double dx, size_t nx, double y0, double dy, size_t ny,
+                                  const double* z, unsigned flags, mi_grid2** out)
+{
+    MI_REQUIRE(ctx, ctx && z && out, "mi_grid2_create_uniform: NULL argument");
+    MI_REQUIRE(ctx, (flags & ~MI_GRID_DEVICE_PTRS) == 0, "mi_grid2_create_uniform: unknown flags 0x%x", flags);
+    *out = nullptr;
+    if (nx < 2 || ny < 2) return mi::fail(ctx, MI_ERR_GRID, "mi_grid2_create_uniform: need at least 2x2 nodes");
+    MI_REQUIRE(ctx, nx < 0x7ffffff0u && ny < 0x7ffffff0u, "mi_grid2_create_uniform: axis too long");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    mi_grid2* g = new (std::nothrow) mi_grid2();
+    if (!g) return mi::fail(ctx, MI_ERR_NOMEM, "mi_grid2_create_uniform: out of host memory");
+    g->ctx = ctx;
+    g->dev_x = g->dev_y = g->dev_z = nullptr;
+    mi_status st = make_uniform_axis(ctx, x0, dx, nx, "x", &g->d.ax);
+    if (st == MI_OK) st = make_uniform_axis(ctx, y0, dy, ny, "y", &g->d.ay);
+    if (st == MI_OK) st = upload_z(ctx, z, nx * ny, flags & MI_GRID_DEVICE_PTRS, &g->dev_z);
+    if (st != MI_OK) { destroy(g); return st; }
+    g->d.z = (const double*)g->dev_z;
+    *out = g;
+    return MI_OK;
+}
+
+mi_status mi_grid2_destroy(mi_grid2* g)
+{
+    if (g) hipSetDevice(g->ctx->device);
+    destroy(g);
+    return MI_OK;
+}
+
+mi_status mi_interp2_f64_dev(mi_ctx* ctx, const mi_grid2* g, const double* xq, const double* yq, double* zq, size_t nq,
+                             double extrap)
+{
+    MI_REQUIRE(ctx, ctx && g, "mi_interp2_f64_dev: NULL context or grid");
+    if (nq == 0) return MI_OK;
+    MI_REQUIRE(ctx, xq && yq && zq, "mi_interp2_f64_dev: NULL query/result pointer");
+    const uintptr_t a = reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq) | reinterpret_cast<uintptr_t>(zq);
+    MI_REQUIRE(ctx, (a & 7u) == 0, "mi_interp2_f64_dev: pointers must be 8-byte aligned");
+    if ((a & 15u) == 0) {
+        const unsigned grid = mi::stream_grid(ctx, (nq + 1) / 2, kBlock);
+        hipLaunchKernelGGL((interp2_kernel<true>), dim3(grid), dim3(kBlock), 0, ctx->stream, g->d, xq, yq, zq, nq, extrap);
+    } else {
+        const unsigned grid = mi::stream_grid(ctx, nq, kBlock);
+        hipLaunchKernelGGL((interp2_kernel<false>), dim3(grid), dim3(kBlock), 0, ctx->stream, g->d, xq, yq, zq, nq, extrap);
+    }
+    MI_LAUNCH_CHECK(ctx, "interp2 kernel");
+    return MI_OK;
+}
+
+mi_status mi_interp2_f64_host(mi_ctx* ctx, const mi_grid2* g, const double* xq, const double* yq, double* zq, size_t nq,
+                              double extrap)
+{
+    MI_REQUIRE(ctx, ctx && g, "mi_interp2_f64_host: NULL context or grid");
+    if (nq == 0) return MI_OK;
+    MI_REQUIRE(ctx, xq && yq && zq, "mi_interp2_f64_host: NULL query/result pointer");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = nq * sizeof(double);
+    mi_status st = MI_OK;
+    for (int s = 0; s < 3 && st == MI_OK; ++s) st = mi::ensure_scratch(ctx, s, bytes);
+    if (st != MI_OK) return st;
+    MI_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], xq, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(ctx, hipMemcpyAsync(ctx->scratch[1], yq, bytes, hipMemcpyHostToDevice, ctx->stream));
+    st = mi_interp2_f64_dev(ctx, g, (const double*)ctx->scratch[0], (const double*)ctx->scratch[1],
+                            (double*)ctx->scratch[2], nq, extrap);
+    if (st != MI_OK) return st;
+    MI_HIP(ctx, hipMemcpyAsync(zq, ctx->scratch[2], bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+
+}  // extern "C"

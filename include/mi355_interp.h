@@ -1,0 +1,217 @@
+/*
+ * mi355_interp.h -- C ABI of libmi355interp.so, the MI355X (gfx950) native
+ * batched linear-interpolation path.
+ *
+ * This is the drop-in boundary for the hot path of
+ * kyle-wedgwood/ArmadilloCUDALinearInterpolation.  The reference has no FFI of
+ * its own (it is one nvcc-built C++ program); what it has is
+ *   - the operator interface  AbstractNonlinearProblem::ComputeF(const
+ *     arma::vec&, arma::vec&)           (AbstractNonlinearProblem.hpp:11), and
+ *   - the device stages that EventDrivenMap::ComputeF launches
+ *     (EventDrivenMap.cu:154-240).
+ * Every entry point below names the reference code it replaces.  The
+ * Armadillo-facing C++ signatures that sit on top of this ABI are in
+ * include/mi355_arma.hpp; the binding a reference maintainer would add is
+ * shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an mi_status (0 = MI_OK) and
+ *     never calls exit() (the reference's CUDA_CALL macros do,
+ *     EventDrivenMap.cu:18-54; the C++ wrapper restores that behaviour).
+ *   - mi_last_error(ctx) returns the message of the last failure on that
+ *     context (or on the calling thread when ctx is NULL).
+ *   - "dev" pointers are HBM addresses valid on the context's device; "host"
+ *     pointers are ordinary host memory.  Device entry points are
+ *     asynchronous on the context's stream and perform no allocation, copy or
+ *     synchronisation (safe to capture into a hipGraph).
+ *   - fp64 blend shared by every interp entry point (Armadillo
+ *     interp1_helper_linear semantics, see oracle/interp_oracle.c):
+ *        l = largest node with X[l] <= q,  r = min(l+1, n-1)
+ *        a = q - X[l];  b = X[r] - q;  w = a > 0 ? a/(a+b) : 0
+ *        out = (1-w)*Y[l] + w*Y[r]          (every op rounded, no FMA)
+ *     q < X[0] or q > X[n-1] -> extrap_val;  q = NaN -> NaN.
+ */
+#ifndef MI355_INTERP_H
+#define MI355_INTERP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_INTERP_ABI_VERSION 1
+
+typedef int mi_status;
+enum {
+    MI_OK = 0,
+    MI_ERR_INVALID_ARG = 1,   /* NULL pointer, bad size, bad flag               */
+    MI_ERR_GRID = 2,          /* grid not sorted/unique, NaN node, < 2 nodes    */
+    MI_ERR_HIP = 3,           /* a HIP runtime call failed (message has detail) */
+    MI_ERR_NOMEM = 4,
+    MI_ERR_NO_DEVICE = 5
+};
+
+typedef struct mi_ctx mi_ctx;       /* one per device (+ stream)            */
+typedef struct mi_grid1 mi_grid1;   /* HBM-resident 1-D table               */
+typedef struct mi_grid2 mi_grid2;   /* HBM-resident 2-D table               */
+typedef struct mi_edm mi_edm;       /* EventDrivenMap device state          */
+typedef struct mi_timer mi_timer;   /* pair of HIP events on the ctx stream */
+
+/* ---- context ---------------------------------------------------------- */
+/* Replaces the implicit "device 0, NULL stream" of the reference
+ * (EventDrivenMap.cu:80-94 allocates on the current device). */
+mi_status mi_ctx_create(int device, mi_ctx** out);
+mi_status mi_ctx_destroy(mi_ctx* ctx);
+/* stream: a hipStream_t (NULL = the device's default stream). */
+mi_status mi_ctx_set_stream(mi_ctx* ctx, void* stream);
+mi_status mi_ctx_synchronize(mi_ctx* ctx);
+const char* mi_last_error(const mi_ctx* ctx);
+int mi_abi_version(void);
+/* name / CU count of the context's device (for bench reports) */
+mi_status mi_ctx_device_info(mi_ctx* ctx, char* name, size_t name_len, int* compute_units,
+                             size_t* hbm_bytes);
+
+/* ---- timing (HIP events recorded on the context's stream) -------------- */
+mi_status mi_timer_create(mi_ctx* ctx, mi_timer** out);
+mi_status mi_timer_destroy(mi_timer* t);
+mi_status mi_timer_start(mi_timer* t);
+mi_status mi_timer_stop(mi_timer* t);
+/* blocks until the stop event has completed */
+mi_status mi_timer_elapsed_ms(mi_timer* t, float* ms);
+
+/* ---- 1-D tables ---------------------------------------------------------
+ * General grid: explicit abscissae, the arma::interp1(X, Y, XI, YI) shape.
+ * x/y are HOST pointers (n doubles each); the table is uploaded once and
+ * stays resident in HBM as interleaved {x,y} nodes.
+ * flags: MI_GRID_SANITISE    sort + de-duplicate X first (what arma::interp1
+ *                            does unless the method is "*linear"); without it
+ *                            X must be strictly increasing or MI_ERR_GRID.
+ *        MI_GRID_DEVICE_PTRS x/y are device pointers (strictly increasing
+ *                            required; validated on device).
+ */
+#define MI_GRID_SANITISE     0x1u
+#define MI_GRID_DEVICE_PTRS  0x2u
+mi_status mi_grid1_create(mi_ctx* ctx, const double* x, const double* y, size_t n,
+                          unsigned flags, mi_grid1** out);
+/* Implicit uniform grid: X_i := fma(i, dx, x0), i = 0..n-1, dx > 0.
+ * Only Y is stored (half the table bytes of the general form). */
+mi_status mi_grid1_create_uniform(mi_ctx* ctx, double x0, double dx, const double* y, size_t n,
+                                  unsigned flags, mi_grid1** out);
+mi_status mi_grid1_destroy(mi_grid1* g);
+/* number of nodes after sanitising; search mode chosen at build time
+ * (0 = implicit uniform, 1 = explicit nodes + analytic guess,
+ *  2 = explicit nodes + bucket index) */
+mi_status mi_grid1_info(const mi_grid1* g, size_t* n_nodes, int* mode, size_t* table_bytes);
+
+/* ---- 1-D interpolation: the hot path -----------------------------------
+ * yq[i] = interp(grid, xq[i]), i < nq.  Device pointers, asynchronous.
+ * Algorithmic HBM bytes per query: 8 (xq) + 8 (yq); the table is read through
+ * L2 / Infinity Cache.
+ * Generalises RestrictKernel's two-point blend (EventDrivenMap.cu:769-785) to
+ * a tabulated grid with a gather index, as BASELINE.json's north_star asks.
+ */
+mi_status mi_interp1_f64_dev(mi_ctx* ctx, const mi_grid1* g, const double* xq_dev, double* yq_dev,
+                             size_t nq, double extrap_val);
+/* Host convenience used by the arma::vec wrapper: uploads xq, runs, downloads
+ * (synchronous). */
+mi_status mi_interp1_f64_host(mi_ctx* ctx, const mi_grid1* g, const double* xq, double* yq,
+                              size_t nq, double extrap_val);
+/* One-shot arma::interp1(X,Y,XI,YI,"linear",extrap) equivalent on host
+ * pointers (sanitises X, builds a temporary table, synchronous). */
+mi_status mi_interp1_f64(mi_ctx* ctx, const double* x, const double* y, size_t n, const double* xq,
+                         double* yq, size_t nq, double extrap_val);
+
+/* ---- 2-D tables and scattered bilinear interpolation ------------------
+ * z is column-major ny x nx, i.e. arma::mat(ny, nx).memptr(): z[i + j*ny] =
+ * Z(y_i, x_j).  Blend along y inside the two bracketing columns, then along
+ * x (oracle/interp_oracle.c orc_interp2_bilinear).  No counterpart in the
+ * reference (BASELINE.json config 3). */
+mi_status mi_grid2_create(mi_ctx* ctx, const double* x, size_t nx, const double* y, size_t ny,
+                          const double* z, unsigned flags, mi_grid2** out);
+mi_status mi_grid2_create_uniform(mi_ctx* ctx, double x0, double dx, size_t nx, double y0, double dy,
+                                  size_t ny, const double* z, unsigned flags, mi_grid2** out);
+mi_status mi_grid2_destroy(mi_grid2* g);
+mi_status mi_interp2_f64_dev(mi_ctx* ctx, const mi_grid2* g, const double* xq_dev,
+                             const double* yq_dev, double* zq_dev, size_t nq, double extrap_val);
+mi_status mi_interp2_f64_host(mi_ctx* ctx, const mi_grid2* g, const double* xq, const double* yq,
+                              double* zq, size_t nq, double extrap_val);
+
+/* ---- the reference's own interpolation ----------------------------------
+ * Replaces RestrictKernel (EventDrivenMap.cu:769-785, launch :205-206):
+ *   x_k = -L + 2L/ngrid * ind_k ;  out = x0 + (T-t0)*(x1-x0)/(t1-t0)   (fp32)
+ * Arrays are [spike][realisation] (index m*R + r), n = S*R elements.  `out`
+ * may alias t0 (the reference works in place).  Device pointers.
+ */
+mi_status mi_restrict_f32_dev(mi_ctx* ctx, const float* t0, const uint16_t* i0, const float* t1,
+                              const uint16_t* i1, float final_time, float half_length,
+                              uint32_t ngrid, float* out, size_t n);
+/* Replaces CountRealisationsKernel + realisationReductionKernelBlocks
+ * (EventDrivenMap.cu:787-824): mean over accepted realisations, per spike.
+ * x: f32[nspikes*nreal] ([spike][realisation]), accept: u32[nreal] (0/1).
+ * mean_dev: f32[nspikes]; count_dev: u32[1]; sums_dev (optional, may be
+ * NULL): f64[nspikes] un-normalised sums for a multi-GPU all-reduce.
+ * quirk != 0 reproduces the reference's accept[0] clobber (realisation 0 is
+ * dropped from the sums unless count == 1).  `accept` is never modified. */
+mi_status mi_masked_mean_f32_dev(mi_ctx* ctx, const float* x, const uint32_t* accept, size_t nreal,
+                                 size_t nspikes, int quirk, float* mean_dev, uint32_t* count_dev,
+                                 double* sums_dev);
+/* Fused Restrict + masked mean: one pass over the 4 event arrays, no
+ * intermediate (what ComputeF uses).  restricted_dev may be NULL. */
+mi_status mi_restrict_mean_f32_dev(mi_ctx* ctx, const float* t0, const uint16_t* i0, const float* t1,
+                                   const uint16_t* i1, const uint32_t* accept, float final_time,
+                                   float half_length, uint32_t ngrid, size_t nreal, size_t nspikes,
+                                   int quirk, float* restricted_dev, float* mean_dev,
+                                   uint32_t* count_dev, double* sums_dev);
+
+/* ---- EventDrivenMap: the residual evaluation ------------------------------
+ * Replaces class EventDrivenMap (EventDrivenMap.hpp:11-121,
+ * EventDrivenMap.cu:57-404): lift -> evolve -> restrict -> average.
+ */
+typedef struct mi_edm_params {
+    float vth, a1, a2, b1, b2, I, L;   /* parameters.hpp:1-8                     */
+    double newton_tol;                 /* parameters.hpp:9  (tol, a double)      */
+    uint32_t newton_max_iter;          /* counterMax: undefined in the reference
+                                          (EventDrivenMap.cu:564); default 100   */
+    uint32_t n_spikes;                 /* parameters.hpp:12 noSpikes (<= 8)      */
+    float time_horizon;                /* parameters.hpp:15                      */
+    uint32_t n_grid;                   /* mNoThreads (EventDrivenMap.cu:70), <= 1024 */
+    uint32_t n_real;                   /* mNoReal                                */
+    float beta_mean;                   /* (*pParameters)[0]                      */
+    float beta_stddev;                 /* mParStdDev (EventDrivenMap.cu:105)     */
+    uint64_t seed;                     /* mSeed                                  */
+    int math_mode;                     /* MI_EDM_MATH_EXACT or MI_EDM_MATH_FAST  */
+    int mean_quirk;                    /* reproduce the accept[0] clobber        */
+} mi_edm_params;
+#define MI_EDM_MATH_EXACT 0   /* software exp/log, bit-identical to oracle/edm_oracle.c */
+#define MI_EDM_MATH_FAST  1   /* v_exp_f32 / v_log_f32 hardware transcendentals          */
+
+void mi_edm_default_params(mi_edm_params* p);
+mi_status mi_edm_create(mi_ctx* ctx, const mi_edm_params* p, mi_edm** out);
+mi_status mi_edm_destroy(mi_edm* e);
+/* setters of EventDrivenMap.hpp:27-51 arrive as a new parameter block */
+mi_status mi_edm_set_params(mi_edm* e, const mi_edm_params* p);
+/* ComputeF (EventDrivenMap.cu:154-240).  z: host, n_spikes doubles (c, Z1..);
+ * f: host, n_spikes doubles.  partial (optional, may be NULL): host,
+ * n_spikes+1 doubles receiving this device's un-normalised sums and accepted
+ * count so that a caller sharding realisations over GPUs can all-reduce them;
+ * when partial is non-NULL f is still the single-device residual. */
+mi_status mi_edm_compute_f(mi_edm* e, const double* z, double* f, double* partial);
+/* f from all-reduced partial sums (host arithmetic of EventDrivenMap.cu:237-239) */
+mi_status mi_edm_residual_from_sums(const mi_edm_params* p, const double* z, const double* sums_and_count,
+                                    double* f);
+/* Debug taps (SaveLift/SaveEvolve/SaveRestrict, EventDrivenMap.cu:406-503):
+ * copy stage outputs of the last compute_f to host.  Any pointer may be NULL.
+ * v,s: f32[n_grid]; t0,t1,restricted: f32[S*R]; i0,i1: u16[S*R]; accept: u32[R] */
+mi_status mi_edm_debug_read(mi_edm* e, float* v, float* s, float* w, float* t0, uint16_t* i0,
+                            float* t1, uint16_t* i1, uint32_t* accept, float* restricted,
+                            uint16_t* seed_ind);
+/* duration of the stages of the last compute_f in ms (HIP events):
+ * [0] lift, [1] evolve, [2] restrict+mean, [3] whole call */
+mi_status mi_edm_last_timings(mi_edm* e, float ms[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_INTERP_H */

@@ -1,0 +1,147 @@
+"""ctypes/numpy front end of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile oracle/*.c -> liboracle.so with the committed Makefile."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE, "clean", "all"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    sz, dbl, i32 = C.c_size_t, C.c_double, C.c_int
+    L.orc_interp1_scan_sorted.argtypes = [_f64p, _f64p, sz, _f64p, sz, dbl, _f64p]
+    L.orc_interp1_scan_sorted.restype = None
+    L.orc_interp1_bracket.argtypes = [_f64p, _f64p, sz, _f64p, sz, dbl, _f64p, i32]
+    L.orc_interp1_bracket.restype = None
+    L.orc_interp1_arma.argtypes = [_f64p, _f64p, sz, _f64p, sz, dbl, _f64p]
+    L.orc_interp1_arma.restype = i32
+    L.orc_interp1_uniform.argtypes = [dbl, dbl, _f64p, sz, _f64p, sz, dbl, _f64p, i32]
+    L.orc_interp1_uniform.restype = None
+    L.orc_interp2_bilinear.argtypes = [_f64p, sz, _f64p, sz, _f64p, _f64p, _f64p, sz, dbl, _f64p, i32]
+    L.orc_interp2_bilinear.restype = None
+    L.orc_interp2_bilinear_uniform.argtypes = [dbl, dbl, sz, dbl, dbl, sz, _f64p, _f64p, _f64p, sz,
+                                               dbl, _f64p, i32]
+    L.orc_interp2_bilinear_uniform.restype = None
+    L.orc_restrict_f32.argtypes = [_f32p, _u16p, _f32p, _u16p, C.c_float, C.c_float, C.c_uint32, _f32p, sz]
+    L.orc_restrict_f32.restype = None
+    L.orc_masked_mean_f32.argtypes = [_f32p, _u32p, sz, sz, i32, _f32p, C.POINTER(C.c_uint32)]
+    L.orc_masked_mean_f32.restype = None
+    L.orc_splitmix_uniform.argtypes = [C.c_uint64, _f64p, sz]
+    L.orc_splitmix_uniform.restype = None
+    L.orc_max_threads.argtypes = []
+    L.orc_max_threads.restype = i32
+    _lib = L
+    return L
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
+
+
+def splitmix_uniform(seed, n):
+    out = np.empty(n, dtype=np.float64)
+    lib().orc_splitmix_uniform(C.c_uint64(seed), out, n)
+    return out
+
+
+def interp1_scan_sorted(xg, yg, xi, extrap=np.nan):
+    xg, yg, xi = _c64(xg), _c64(yg), _c64(xi)
+    out = np.empty_like(xi)
+    lib().orc_interp1_scan_sorted(xg, yg, xg.size, xi, xi.size, extrap, out)
+    return out
+
+
+def interp1_bracket(xg, yg, xi, extrap=np.nan, nthreads=1):
+    xg, yg, xi = _c64(xg), _c64(yg), _c64(xi)
+    out = np.empty_like(xi)
+    lib().orc_interp1_bracket(xg, yg, xg.size, xi, xi.size, extrap, out, nthreads)
+    return out
+
+
+def interp1_arma(x, y, xi, extrap=np.nan):
+    x, y, xi = _c64(x), _c64(y), _c64(xi)
+    out = np.empty_like(xi)
+    rc = lib().orc_interp1_arma(x, y, x.size, xi, xi.size, extrap, out)
+    if rc != 0:
+        raise ValueError("orc_interp1_arma failed with code %d" % rc)
+    return out
+
+
+def interp1_uniform(x0, dx, yg, xi, extrap=np.nan, nthreads=1):
+    yg, xi = _c64(yg), _c64(xi)
+    out = np.empty_like(xi)
+    lib().orc_interp1_uniform(x0, dx, yg, yg.size, xi, xi.size, extrap, out, nthreads)
+    return out
+
+
+def interp2_bilinear(xg, yg, z, xq, yq, extrap=np.nan, nthreads=1):
+    """z: (ny, nx) array; passed to C in column-major (arma::mat) layout."""
+    xg, yg, xq, yq = _c64(xg), _c64(yg), _c64(xq), _c64(yq)
+    z = np.asarray(z, dtype=np.float64)
+    assert z.shape == (yg.size, xg.size)
+    zcm = np.ascontiguousarray(z.T).reshape(-1)      # column-major flat
+    out = np.empty_like(xq)
+    lib().orc_interp2_bilinear(xg, xg.size, yg, yg.size, zcm, xq, yq, xq.size, extrap, out, nthreads)
+    return out
+
+
+def interp2_bilinear_uniform(x0, dx, nx, y0, dy, ny, z, xq, yq, extrap=np.nan, nthreads=1):
+    xq, yq = _c64(xq), _c64(yq)
+    z = np.asarray(z, dtype=np.float64)
+    assert z.shape == (ny, nx)
+    zcm = np.ascontiguousarray(z.T).reshape(-1)
+    out = np.empty_like(xq)
+    lib().orc_interp2_bilinear_uniform(x0, dx, nx, y0, dy, ny, zcm, xq, yq, xq.size, extrap, out, nthreads)
+    return out
+
+
+def restrict_f32(t0, i0, t1, i1, T, L, ngrid):
+    t0 = np.ascontiguousarray(t0, dtype=np.float32)
+    t1 = np.ascontiguousarray(t1, dtype=np.float32)
+    i0 = np.ascontiguousarray(i0, dtype=np.uint16)
+    i1 = np.ascontiguousarray(i1, dtype=np.uint16)
+    out = np.empty_like(t0)
+    lib().orc_restrict_f32(t0, i0, t1, i1, T, L, ngrid, out, t0.size)
+    return out
+
+
+def masked_mean_f32(x, accept, nspikes, quirk=False):
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    accept = np.ascontiguousarray(accept, dtype=np.uint32)
+    nreal = accept.size
+    assert x.size == nspikes * nreal
+    mean = np.empty(nspikes, dtype=np.float32)
+    cnt = C.c_uint32(0)
+    lib().orc_masked_mean_f32(x, accept, nreal, nspikes, int(bool(quirk)), mean, C.byref(cnt))
+    return mean, int(cnt.value)
