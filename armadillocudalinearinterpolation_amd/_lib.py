@@ -34,6 +34,7 @@ class EdmParams(C.Structure):
         ("seed", C.c_uint64),
         ("math_mode", C.c_int),
         ("mean_quirk", C.c_int),
+        ("real_offset", C.c_uint32),
     ]
 
 
@@ -79,6 +80,7 @@ SIGNATURES = {
     "mi_edm_residual_from_sums": (_i32, [C.POINTER(EdmParams), _vp, _vp, _vp]),
     "mi_edm_debug_read": (_i32, [_vp] + [_vp] * 10),
     "mi_edm_last_timings": (_i32, [_vp, C.POINTER(_f32 * 4)]),
+    "mi_edm_math_probe": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _sz]),
 }
 
 

@@ -1,0 +1,601 @@
+// EventDrivenMap residual on MI355X: lift -> evolve -> restrict -> average
+// (replaces EventDrivenMap.cu:57-404, 505-674 of the reference).
+//
+// MI355X-first structure (not the reference's launch shapes):
+//   * Lift (EventDrivenMap.cu:505-542) does not depend on the realisation, so
+//     it runs ONCE per ComputeF on N lanes (the reference runs it R times and
+//     writes 8*R*N bytes); Evolve reads the N-point profile from L2.
+//   * Evolve: ONE WAVE64 PER REALISATION, each lane owning N/64 neurons in
+//     lane-private LDS slots (neuron i = k*64 + lane).  The reference uses one 1024-thread
+//     block per realisation with two __syncthreads() and a shared-memory
+//     arg-min per event (EventDrivenMap.cu:601-645, 855-881); here the
+//     arg-min is 6 wave shuffles, there is no barrier in the event loop, and
+//     the coupling table sits in LDS.  beta is generated on the fly from a
+//     counter-based hash (no 4*R*N-byte beta array, no RNG library).
+//   * Restrict + masked mean: the fused single-pass kernel of mi_restrict.hip.
+//   * U and the seed indices travel as kernel arguments: no H2D copies; one
+//     D2H copy of S+1 scalars per ComputeF (the reference: 3 small copies).
+// Arithmetic: csrc/mi_edm_math.hpp == oracle/edm_oracle.c (bit-exact in
+// MI_EDM_MATH_EXACT mode).  Documented decisions [D1]-[D7]: DESIGN.md.
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "mi_common.hpp"
+#include "mi_edm_math.hpp"
+
+namespace {
+
+constexpr int kMaxSpikes = 8;
+constexpr int kMaxGrid = 1024;
+constexpr int kEvolveBlock = 256;   // 4 waves = 4 realisations per workgroup
+
+struct SpikeSeeds {
+    float U[kMaxSpikes + 1];        // (c, 0, Z1, ..), fp32 (EventDrivenMap.cu:172)
+    unsigned short ind[kMaxSpikes]; // initialSpikeInd, EventDrivenMap.cu:361-372
+};
+
+// ---- LiftKernel (EventDrivenMap.cu:505-542), once per ComputeF -------------
+template <int MATH>
+__global__ __launch_bounds__(kMaxGrid) void lift_kernel(edm::Model M, SpikeSeeds sd, float* __restrict__ v,
+                                                        float* __restrict__ s)
+{
+    const unsigned i = threadIdx.x;
+    if (i >= M.N) return;
+    const float c = sd.U[0], beta = M.beta_mean;
+    const float a[2] = {M.a1, M.a2}, b[2] = {M.b1, M.b2};
+    const float h = (2.0f * M.L) / (float)M.N;
+    const float omb = 1.0f - beta;
+    const float x = M.L - h * (float)i;
+    const float xc = x / c;
+    float sv = 0.0f, ss = 0.0f;
+    for (unsigned m = 1; m <= M.S; ++m) {
+        const float Um = sd.U[m];
+        const float cu = c * Um;
+        const float d = x - cu;
+        const float pos = (d > 0.0f) ? 1.0f : 0.0f;
+        const float neg = (d <= 0.0f) ? 1.0f : 0.0f;
+        float brA = 0.0f, brB = 0.0f, sa = 0.0f, sb = 0.0f;
+        const float ebu = edm::expf_<MATH>(beta * Um);
+        const float dx = edm::expf_<MATH>(xc * omb) - edm::expf_<MATH>(Um * omb);
+        const float ebc = edm::expf_<MATH>(-(beta / c) * d);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float sg = (k == 0) ? 1.0f : -1.0f;
+            const float cb = c * b[k];
+            const float abc = (a[k] * beta) * c;
+            const float Pk = abc / ((beta + cb) * (1.0f + cb));
+            const float Qk = abc / omb;
+            const float Rk = abc / ((cb - beta) * (1.0f - cb));
+            const float gk = 1.0f / (beta + cb) + 1.0f / (cb - beta);
+            const float ep = (1.0f + cb) / c;
+            const float em = (1.0f - cb) / c;
+            const float en = edm::expf_<MATH>(-(b[k] * cu));
+            const float epos = edm::expf_<MATH>(b[k] * cu);
+            const float tA = (Pk * edm::expf_<MATH>(cu * ep)) * en + ((Qk * ebu) * gk) * dx -
+                             (Rk * epos) * (edm::expf_<MATH>(x * em) - edm::expf_<MATH>(cu * em));
+            const float tB = (Pk * edm::expf_<MATH>(x * ep)) * en;
+            brA = brA + sg * tA;
+            brB = brB + sg * tB;
+            const float ta = ((beta * a[k]) * (c / (beta + cb))) * edm::expf_<MATH>(b[k] * d);
+            const float tb = (((2.0f * a[k]) / b[k]) * (beta / (1.0f - (beta * beta) / (((c * c) * b[k]) * b[k])))) * ebc -
+                             ((beta * a[k]) * (c / (cb - beta))) * edm::expf_<MATH>(b[k] * (cu - x));
+            sa = sa + sg * ta;
+            sb = sb + sg * tb;
+        }
+        const float dummyV = (pos * brA + neg * brB) * edm::expf_<MATH>(-xc);
+        sv = sv + (dummyV - pos * edm::expf_<MATH>(-d / c));
+        const float e = cu - x;
+        const float posS = (e > 0.0f) ? 1.0f : 0.0f;
+        const float negS = (e <= 0.0f) ? 1.0f : 0.0f;
+        ss = ss + (posS * sa + negS * sb);
+    }
+    float vv = M.I + sv;
+    vv = vv * ((vv < 1.0f) ? 1.0f : 0.0f);
+    v[i] = vv;
+    s[i] = ss;
+}
+
+// ---- EvolveKernel (EventDrivenMap.cu:575-674): one wave64 per realisation ----
+// Neuron state lives in LDS, [wave][array][k*64 + lane]: every lane only ever
+// touches its own slots, so the event loop needs no barrier and the per-neuron
+// loop stays rolled (few VGPRs -> 3 workgroups per CU at N = 1024).
+// LDS per workgroup: w[1024] + 4 waves * (2 or 3) arrays * npl*64 floats.
+template <int MATH, bool HETERO>
+__global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, SpikeSeeds sd,
+                                                              const float* __restrict__ v0,
+                                                              const float* __restrict__ s0,
+                                                              const float* __restrict__ w,
+                                                              float* __restrict__ g_t0,
+                                                              unsigned short* __restrict__ g_i0,
+                                                              float* __restrict__ g_t1,
+                                                              unsigned short* __restrict__ g_i1,
+                                                              unsigned* __restrict__ g_accept)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned npl = (M.N + 63u) / 64u;
+    const unsigned slots = npl * 64u;
+    float* w_lds = lds;
+    for (unsigned i = threadIdx.x; i < (unsigned)kMaxGrid; i += kEvolveBlock) w_lds[i] = (i < M.N) ? w[i] : 0.0f;
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    constexpr unsigned kArrays = HETERO ? 3u : 2u;
+    float* V = lds + kMaxGrid + (size_t)wave * kArrays * slots;
+    float* S = V + slots;
+    float* B = S + slots;   // only touched when HETERO
+    const unsigned waves_per_grid = gridDim.x * (kEvolveBlock / 64);
+    const unsigned full = (1u << M.S) - 1u;
+    const float two_T = 2.0f * M.T;
+
+    for (unsigned r = blockIdx.x * (kEvolveBlock / 64) + wave; r < M.R; r += waves_per_grid) {
+        for (unsigned k = 0; k < npl; ++k) {
+            const unsigned i = k * 64u + lane;
+            const bool act = i < M.N;
+            V[i] = act ? v0[i] : 0.0f;
+            S[i] = act ? s0[i] : 0.0f;
+            if constexpr (HETERO) B[i] = edm::beta_of<MATH>(M.beta_mean, M.beta_sigma, M.seed, M.N, (uint64_t)r + M.real_offset, act ? i : 0u);
+        }
+        // per-bump event slots ([D2]: start at time 0 / index 0); wave-uniform values
+        float lt[kMaxSpikes], ct[kMaxSpikes];
+        unsigned li[kMaxSpikes], ci[kMaxSpikes];
+#pragma unroll
+        for (int m = 0; m < kMaxSpikes; ++m) {
+            lt[m] = 0.0f;
+            ct[m] = 0.0f;
+            ci[m] = 0u;
+            li[m] = (m < (int)M.S) ? (unsigned)sd.ind[m] : 0u;
+        }
+        unsigned crossed = 0;
+        float now = 0.0f;
+        while (crossed < full && now < two_T) {
+            // next firing time of every neuron; lane-local then wave arg-min
+            // ([D1]: smallest time, ties -> lowest index, NaN never wins)
+            float best = INFINITY;
+            unsigned idx = 0;
+            for (unsigned k = 0; k < npl; ++k) {
+                const unsigned i = k * 64u + lane;
+                if (i < M.N) {
+                    const float bk = HETERO ? B[i] : M.beta_mean;
+                    const float tau = edm::event_time<MATH>(M, V[i], S[i], bk);
+                    if (tau < best) { best = tau; idx = i; }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ot = __shfl_xor(best, off, 64);
+                const unsigned oi = __shfl_xor(idx, off, 64);
+                if (ot < best || (ot == best && oi < idx)) { best = ot; idx = oi; }
+            }
+            const float dt = best;
+            // analytic state advance (EventDrivenMap.cu:612-617)
+            const float e1 = edm::expf_<MATH>(-dt);
+            float e2u = 0.0f, e3u = 0.0f;
+            if constexpr (!HETERO) {
+                e2u = edm::expf_<MATH>((1.0f - M.beta_mean) * dt);
+                e3u = edm::expf_<MATH>(-M.beta_mean * dt);
+            }
+            for (unsigned k = 0; k < npl; ++k) {
+                const unsigned i = k * 64u + lane;
+                const float bk = HETERO ? B[i] : M.beta_mean;
+                const float e2 = HETERO ? edm::expf_<MATH>((1.0f - bk) * dt) : e2u;
+                const float e3 = HETERO ? edm::expf_<MATH>(-bk * dt) : e3u;
+                const float so = S[i];
+                float vv = V[i] * e1;
+                vv = vv + (M.I * (1.0f - e1) + ((so * e1) / (1.0f - bk)) * (e2 - 1.0f));
+                vv = vv * ((i != idx) ? 1.0f : 0.0f);
+                float sn = so * e3;
+                const unsigned dist = (i >= idx) ? (i - idx) : (idx - i);
+                sn = sn + bk * w_lds[dist & (kMaxGrid - 1)];
+                V[i] = vv;
+                S[i] = sn;
+            }
+            now = now + dt;
+            // which bump does the event belong to ([D3]: the reference's increment rule, :625-629)
+            unsigned mi = 0;
+#pragma unroll
+            for (int m = 1; m < kMaxSpikes; ++m) {
+                if (m < (int)M.S) {
+                    unsigned lmi = li[0];
+#pragma unroll
+                    for (int j = 1; j < kMaxSpikes; ++j) lmi = (mi == (unsigned)j) ? li[j] : lmi;
+                    const int dm = abs((int)idx - (int)li[m]);
+                    const int d0 = abs((int)idx - (int)lmi);
+                    mi += (dm < d0) ? 1u : 0u;
+                }
+            }
+            if (!(crossed & (1u << mi))) {
+                const bool after = now > M.T;
+#pragma unroll
+                for (int m = 0; m < kMaxSpikes; ++m) {
+                    if (mi == (unsigned)m) {
+                        if (after) { ct[m] = now; ci[m] = idx; }
+                        else { lt[m] = now; li[m] = idx; }
+                    }
+                }
+                if (after) crossed += (1u << mi);
+            }
+        }
+        // [spike][realisation] layout, EventDrivenMap.cu:661-668
+#pragma unroll
+        for (int m = 0; m < kMaxSpikes; ++m) {
+            if (lane == (unsigned)m && m < (int)M.S) {
+                const size_t k = (size_t)m * M.R + r;
+                g_t0[k] = lt[m];
+                g_i0[k] = (unsigned short)li[m];
+                g_t1[k] = ct[m];
+                g_i1[k] = (unsigned short)ci[m];
+            }
+        }
+        if (lane == 0) g_accept[r] = (crossed == full) ? 1u : 0u;
+    }
+}
+
+template <int MATH>
+__global__ void math_probe_kernel(int op, const float* a, const float* b, float* out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (op) {
+        case 0: r = edm::expf_<MATH>(a[i]); break;
+        case 1: r = edm::logf_<MATH>(a[i]); break;
+        case 2: r = edm::powf_<MATH>(a[i], b[i]); break;
+        default: r = edm::erfinvf_<MATH>(a[i]); break;
+    }
+    out[i] = r;
+}
+
+}  // namespace
+
+struct mi_edm {
+    mi_ctx* ctx;
+    mi_edm_params p;
+    edm::Model M;
+    // device state
+    float *d_v = nullptr, *d_s = nullptr, *d_w = nullptr;
+    float *d_t0 = nullptr, *d_t1 = nullptr, *d_restricted = nullptr;
+    uint16_t *d_i0 = nullptr, *d_i1 = nullptr;
+    uint32_t* d_accept = nullptr;
+    char* d_result = nullptr;      // mean f32[8] | count u32 (+pad) | sums f64[8]
+    char* h_result = nullptr;      // pinned mirror
+    size_t alloc_real = 0;
+    bool w_valid = false;
+    bool have_run = false;
+    uint16_t seed_ind[kMaxSpikes] = {0};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float last_ms[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+constexpr size_t kResultBytes = 8 * 4 + 8 + 8 * 8;
+
+mi_status validate(const mi_ctx* ctx, const mi_edm_params* p)
+{
+    if (!p) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: params is NULL");
+    if (p->n_spikes < 1 || p->n_spikes > (uint32_t)kMaxSpikes)
+        return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: n_spikes=%u not in [1,%d]", p->n_spikes, kMaxSpikes);
+    if (p->n_grid < 2 || p->n_grid > (uint32_t)kMaxGrid)
+        return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: n_grid=%u not in [2,%d]", p->n_grid, kMaxGrid);
+    if (p->n_real < 1) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: n_real must be positive");
+    if (!(p->time_horizon > 0.0f)) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: time_horizon must be > 0");
+    if (!(p->beta_stddev >= 0.0f)) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: beta_stddev must be >= 0");
+    if (p->math_mode != MI_EDM_MATH_EXACT && p->math_mode != MI_EDM_MATH_FAST)
+        return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: unknown math_mode %d", p->math_mode);
+    if ((uint64_t)p->n_spikes * p->n_real > 0xfffffff0ull)
+        return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: n_spikes*n_real too large");
+    return MI_OK;
+}
+
+void fill_model(const mi_edm_params& p, edm::Model* M)
+{
+    M->vth = p.vth; M->a1 = p.a1; M->a2 = p.a2; M->b1 = p.b1; M->b2 = p.b2; M->I = p.I; M->L = p.L;
+    float tf = (float)p.newton_tol;
+    if ((double)tf > p.newton_tol) tf = nextafterf(tf, -INFINITY);
+    M->tol_f = tf;
+    M->max_iter = p.newton_max_iter;
+    M->S = p.n_spikes; M->N = p.n_grid; M->R = p.n_real;
+    M->T = p.time_horizon;
+    M->beta_mean = p.beta_mean; M->beta_sigma = p.beta_stddev;
+    M->seed = p.seed;
+    M->real_offset = p.real_offset;
+}
+
+void free_real_buffers(mi_edm* e)
+{
+    void* bufs[] = {e->d_t0, e->d_t1, e->d_restricted, e->d_i0, e->d_i1, e->d_accept};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    e->d_t0 = e->d_t1 = e->d_restricted = nullptr;
+    e->d_i0 = e->d_i1 = nullptr;
+    e->d_accept = nullptr;
+    e->alloc_real = 0;
+}
+
+mi_status ensure_buffers(mi_edm* e)
+{
+    mi_ctx* ctx = e->ctx;
+    const size_t SR = (size_t)kMaxSpikes * e->p.n_real;   // sized for any n_spikes
+    if (e->alloc_real >= e->p.n_real) return MI_OK;
+    free_real_buffers(e);
+    MI_HIP(ctx, hipMalloc(&e->d_t0, SR * sizeof(float)));
+    MI_HIP(ctx, hipMalloc(&e->d_t1, SR * sizeof(float)));
+    MI_HIP(ctx, hipMalloc(&e->d_restricted, SR * sizeof(float)));
+    MI_HIP(ctx, hipMalloc(&e->d_i0, SR * sizeof(uint16_t)));
+    MI_HIP(ctx, hipMalloc(&e->d_i1, SR * sizeof(uint16_t)));
+    MI_HIP(ctx, hipMalloc(&e->d_accept, (size_t)e->p.n_real * sizeof(uint32_t)));
+    e->alloc_real = e->p.n_real;
+    return MI_OK;
+}
+
+// BuildCouplingKernel + circshift (EventDrivenMap.cu:111-129, :826-841), on the host
+template <int MATH>
+void build_coupling(const mi_edm_params& p, float* w)
+{
+    const uint32_t N = p.n_grid;
+    std::vector<float> tmp(N);
+    const float h = (2.0f * p.L) / (float)N;
+    for (uint32_t i = 0; i < N; ++i) {
+        const float x = -p.L + h * (float)i;
+        const float ax = fabsf(x);
+        const float k = p.a1 * edm::expf_<MATH>(-p.b1 * ax) - p.a2 * edm::expf_<MATH>(-p.b2 * ax);
+        tmp[i] = ((k * 2.0f) * p.L) / (float)N;
+    }
+    const uint32_t shift = N / 2;
+    for (uint32_t i = 0; i < N; ++i) w[i] = tmp[(i + shift) % N];
+}
+
+// initialSpikeInd (EventDrivenMap.cu:361-372); [D5] stale entries persist in e->seed_ind
+void seed_indices(const mi_edm_params& p, const double* Z, uint16_t* ind)
+{
+    const uint32_t N = p.n_grid, S = p.n_spikes;
+    ind[0] = (uint16_t)(N / 2);
+    for (uint32_t m = 1; m < S; ++m) {
+        for (uint32_t i = ind[m - 1]; i > 0; --i) {
+            const float xi = -p.L + ((float)(2u * i) * p.L) / (float)N;
+            if ((double)xi < -Z[0] * Z[m]) {
+                ind[m] = (uint16_t)i;
+                break;
+            }
+        }
+    }
+}
+
+template <int MATH>
+mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd)
+{
+    mi_ctx* ctx = e->ctx;
+    const unsigned N = e->p.n_grid, R = e->p.n_real;
+    const unsigned slots = ((N + 63) / 64) * 64;
+    const bool hetero = e->p.beta_stddev != 0.0f;
+    const size_t lds_bytes = ((size_t)kMaxGrid + (size_t)(kEvolveBlock / 64) * (hetero ? 3 : 2) * slots) * sizeof(float);
+    unsigned blocks = (R + 3) / 4;
+    // grid-stride over realisations: enough workgroups for every CU at the LDS-limited residency
+    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
+    const unsigned cap = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256) * per_cu * 4u;
+    if (blocks > cap) blocks = cap;
+    if (hetero)
+        hipLaunchKernelGGL((evolve_kernel<MATH, true>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, e->M, sd,
+                           e->d_v, e->d_s, e->d_w, e->d_t0, e->d_i0, e->d_t1, e->d_i1, e->d_accept);
+    else
+        hipLaunchKernelGGL((evolve_kernel<MATH, false>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, e->M, sd,
+                           e->d_v, e->d_s, e->d_w, e->d_t0, e->d_i0, e->d_t1, e->d_i1, e->d_accept);
+    MI_LAUNCH_CHECK(ctx, "evolve kernel");
+    return MI_OK;
+}
+
+template <int MATH>
+mi_status run_pipeline(mi_edm* e, const SpikeSeeds& sd)
+{
+    mi_ctx* ctx = e->ctx;
+    if (!e->w_valid) {
+        std::vector<float> w(e->p.n_grid);
+        build_coupling<MATH>(e->p, w.data());
+        MI_HIP(ctx, hipMemcpyAsync(e->d_w, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(ctx, hipStreamSynchronize(ctx->stream));   // w is a stack-lifetime host buffer
+        e->w_valid = true;
+    }
+    MI_HIP(ctx, hipEventRecord(e->ev[0], ctx->stream));
+    hipLaunchKernelGGL((lift_kernel<MATH>), dim3(1), dim3(kMaxGrid), 0, ctx->stream, e->M, sd, e->d_v, e->d_s);
+    MI_LAUNCH_CHECK(ctx, "lift kernel");
+    MI_HIP(ctx, hipEventRecord(e->ev[1], ctx->stream));
+    mi_status st = launch_evolve<MATH>(e, sd);
+    if (st != MI_OK) return st;
+    MI_HIP(ctx, hipEventRecord(e->ev[2], ctx->stream));
+    st = mi_restrict_mean_f32_dev(ctx, e->d_t0, e->d_i0, e->d_t1, e->d_i1, e->d_accept, e->p.time_horizon, e->p.L,
+                                  e->p.n_grid, e->p.n_real, e->p.n_spikes, e->p.mean_quirk, nullptr,
+                                  (float*)e->d_result, (uint32_t*)(e->d_result + 32), (double*)(e->d_result + 40));
+    if (st != MI_OK) return st;
+    MI_HIP(ctx, hipEventRecord(e->ev[3], ctx->stream));
+    MI_HIP(ctx, hipMemcpyAsync(e->h_result, e->d_result, kResultBytes, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void mi_edm_default_params(mi_edm_params* p)
+{
+    if (!p) return;
+    // parameters.hpp:1-15; Driver.cu:16,19; counterMax := 100 (undefined upstream, EventDrivenMap.cu:564)
+    p->vth = 1.0f; p->a1 = 11.0f; p->a2 = 7.0f; p->b1 = 5.0f; p->b2 = 3.5f; p->I = 0.9f; p->L = 3.0f;
+    p->newton_tol = 1e-6;
+    p->newton_max_iter = 100;
+    p->n_spikes = 3;
+    p->time_horizon = 5.0f;
+    p->n_grid = 1024;
+    p->n_real = 1000;
+    p->beta_mean = 13.0589f;
+    p->beta_stddev = 0.0f;
+    p->seed = 0x5EED0005ull;
+    p->math_mode = MI_EDM_MATH_EXACT;
+    p->mean_quirk = 0;
+    p->real_offset = 0;
+}
+
+mi_status mi_edm_create(mi_ctx* ctx, const mi_edm_params* p, mi_edm** out)
+{
+    MI_REQUIRE(ctx, ctx && out, "mi_edm_create: NULL argument");
+    *out = nullptr;
+    mi_status st = validate(ctx, p);
+    if (st != MI_OK) return st;
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    mi_edm* e = new (std::nothrow) mi_edm();
+    if (!e) return mi::fail(ctx, MI_ERR_NOMEM, "mi_edm_create: out of host memory");
+    e->ctx = ctx;
+    e->p = *p;
+    fill_model(e->p, &e->M);
+    hipError_t err = hipSuccess;
+    if (err == hipSuccess) err = hipMalloc(&e->d_v, kMaxGrid * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&e->d_s, kMaxGrid * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&e->d_w, kMaxGrid * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&e->d_result, kResultBytes);
+    if (err == hipSuccess) err = hipHostMalloc(&e->h_result, kResultBytes);
+    for (int i = 0; i < 4 && err == hipSuccess; ++i) err = hipEventCreate(&e->ev[i]);
+    if (err != hipSuccess) {
+        mi_edm_destroy(e);
+        return mi::fail(ctx, MI_ERR_HIP, "mi_edm_create: allocation failed: %s", hipGetErrorString(err));
+    }
+    st = ensure_buffers(e);
+    if (st != MI_OK) { mi_edm_destroy(e); return st; }
+    *out = e;
+    return MI_OK;
+}
+
+mi_status mi_edm_destroy(mi_edm* e)
+{
+    if (!e) return MI_OK;
+    (void)hipSetDevice(e->ctx->device);
+    free_real_buffers(e);
+    void* bufs[] = {e->d_v, e->d_s, e->d_w, e->d_result};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (e->h_result) (void)hipHostFree(e->h_result);
+    for (int i = 0; i < 4; ++i)
+        if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    delete e;
+    return MI_OK;
+}
+
+mi_status mi_edm_set_params(mi_edm* e, const mi_edm_params* p)
+{
+    MI_REQUIRE(nullptr, e != nullptr, "mi_edm_set_params: handle is NULL");
+    mi_ctx* ctx = e->ctx;
+    mi_status st = validate(ctx, p);
+    if (st != MI_OK) return st;
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    const bool w_same = e->w_valid && p->n_grid == e->p.n_grid && p->L == e->p.L && p->a1 == e->p.a1 &&
+                        p->a2 == e->p.a2 && p->b1 == e->p.b1 && p->b2 == e->p.b2 && p->math_mode == e->p.math_mode;
+    MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    e->p = *p;
+    fill_model(e->p, &e->M);
+    e->w_valid = w_same;
+    e->have_run = false;
+    return ensure_buffers(e);
+}
+
+mi_status mi_edm_compute_f(mi_edm* e, const double* z, double* f, double* partial)
+{
+    MI_REQUIRE(nullptr, e != nullptr, "mi_edm_compute_f: handle is NULL");
+    mi_ctx* ctx = e->ctx;
+    MI_REQUIRE(ctx, z && f, "mi_edm_compute_f: NULL vector");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t S = e->p.n_spikes;
+    // ZtoU (EventDrivenMap.cu:388-396) and the fp64 -> fp32 cast of :172
+    double U0[kMaxSpikes + 1];
+    U0[0] = z[0];
+    U0[1] = 0.0;
+    for (uint32_t i = 2; i <= S; ++i) U0[i] = z[i - 1];
+    SpikeSeeds sd;
+    memset(&sd, 0, sizeof(sd));
+    for (uint32_t i = 0; i <= S; ++i) sd.U[i] = (float)U0[i];
+    seed_indices(e->p, z, e->seed_ind);
+    for (uint32_t m = 0; m < S; ++m) sd.ind[m] = e->seed_ind[m];
+    mi_status st = (e->p.math_mode == MI_EDM_MATH_FAST) ? run_pipeline<1>(e, sd) : run_pipeline<0>(e, sd);
+    if (st != MI_OK) return st;
+    e->have_run = true;
+    for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&e->last_ms[i], e->ev[i], e->ev[i + 1]);
+    (void)hipEventElapsedTime(&e->last_ms[3], e->ev[0], e->ev[3]);
+    const float* mean = (const float*)e->h_result;
+    const uint32_t count = *(const uint32_t*)(e->h_result + 32);
+    const double* sums = (const double*)(e->h_result + 40);
+    // host epilogue, EventDrivenMap.cu:237-239 (fp64)
+    for (uint32_t m = 0; m < S; ++m) f[m] = (-U0[0] * U0[m + 1] - (double)mean[m]) + U0[0] * (double)e->p.time_horizon;
+    if (partial) {
+        for (uint32_t m = 0; m < S; ++m) partial[m] = sums[m];
+        partial[S] = (double)count;
+    }
+    return MI_OK;
+}
+
+mi_status mi_edm_residual_from_sums(const mi_edm_params* p, const double* z, const double* sc, double* f)
+{
+    if (!p || !z || !sc || !f) return mi::fail(nullptr, MI_ERR_INVALID_ARG, "mi_edm_residual_from_sums: NULL argument");
+    const uint32_t S = p->n_spikes;
+    if (S < 1 || S > (uint32_t)kMaxSpikes) return mi::fail(nullptr, MI_ERR_INVALID_ARG, "mi_edm_residual_from_sums: bad n_spikes");
+    double U0[kMaxSpikes + 1];
+    U0[0] = z[0];
+    U0[1] = 0.0;
+    for (uint32_t i = 2; i <= S; ++i) U0[i] = z[i - 1];
+    const double count = sc[S];
+    for (uint32_t m = 0; m < S; ++m) {
+        // same rounding as the single-device path: fp64 sum -> fp32, fp32 division by the count
+        const float mean = (float)sc[m] / (float)count;
+        f[m] = (-U0[0] * U0[m + 1] - (double)mean) + U0[0] * (double)p->time_horizon;
+    }
+    return MI_OK;
+}
+
+mi_status mi_edm_debug_read(mi_edm* e, float* v, float* s, float* w, float* t0, uint16_t* i0, float* t1,
+                            uint16_t* i1, uint32_t* accept, float* restricted, uint16_t* seed_ind)
+{
+    MI_REQUIRE(nullptr, e != nullptr, "mi_edm_debug_read: handle is NULL");
+    mi_ctx* ctx = e->ctx;
+    MI_REQUIRE(ctx, e->have_run, "mi_edm_debug_read: no ComputeF has run with the current parameters");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t N = e->p.n_grid, SR = (size_t)e->p.n_spikes * e->p.n_real;
+    if (restricted) {
+        mi_status st = mi_restrict_f32_dev(ctx, e->d_t0, e->d_i0, e->d_t1, e->d_i1, e->p.time_horizon, e->p.L,
+                                           e->p.n_grid, e->d_restricted, SR);
+        if (st != MI_OK) return st;
+    }
+    MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (v) MI_HIP(ctx, hipMemcpy(v, e->d_v, N * sizeof(float), hipMemcpyDeviceToHost));
+    if (s) MI_HIP(ctx, hipMemcpy(s, e->d_s, N * sizeof(float), hipMemcpyDeviceToHost));
+    if (w) MI_HIP(ctx, hipMemcpy(w, e->d_w, N * sizeof(float), hipMemcpyDeviceToHost));
+    if (t0) MI_HIP(ctx, hipMemcpy(t0, e->d_t0, SR * sizeof(float), hipMemcpyDeviceToHost));
+    if (i0) MI_HIP(ctx, hipMemcpy(i0, e->d_i0, SR * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    if (t1) MI_HIP(ctx, hipMemcpy(t1, e->d_t1, SR * sizeof(float), hipMemcpyDeviceToHost));
+    if (i1) MI_HIP(ctx, hipMemcpy(i1, e->d_i1, SR * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    if (accept) MI_HIP(ctx, hipMemcpy(accept, e->d_accept, (size_t)e->p.n_real * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (restricted) MI_HIP(ctx, hipMemcpy(restricted, e->d_restricted, SR * sizeof(float), hipMemcpyDeviceToHost));
+    if (seed_ind) memcpy(seed_ind, e->seed_ind, e->p.n_spikes * sizeof(uint16_t));
+    return MI_OK;
+}
+
+mi_status mi_edm_last_timings(mi_edm* e, float ms[4])
+{
+    MI_REQUIRE(nullptr, e && ms, "mi_edm_last_timings: NULL argument");
+    for (int i = 0; i < 4; ++i) ms[i] = e->last_ms[i];
+    return MI_OK;
+}
+
+// test hook: run the device math routines on arrays (op: 0 exp, 1 log, 2 pow, 3 erfinv)
+mi_status mi_edm_math_probe(mi_ctx* ctx, int math_mode, int op, const float* a_dev, const float* b_dev,
+                            float* out_dev, size_t n)
+{
+    MI_REQUIRE(ctx, ctx && a_dev && out_dev, "mi_edm_math_probe: NULL argument");
+    if (n == 0) return MI_OK;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (math_mode == MI_EDM_MATH_FAST)
+        hipLaunchKernelGGL((math_probe_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, op, a_dev, b_dev ? b_dev : a_dev, out_dev, n);
+    else
+        hipLaunchKernelGGL((math_probe_kernel<0>), dim3(grid), dim3(256), 0, ctx->stream, op, a_dev, b_dev ? b_dev : a_dev, out_dev, n);
+    MI_LAUNCH_CHECK(ctx, "math probe kernel");
+    return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+// fp32 arithmetic of the EventDrivenMap pipeline on gfx950 (and on the host for
+// the coupling table).  MATH = 0 (MI_EDM_MATH_EXACT): software exp/log built
+// only from IEEE operations and explicit fmaf -- bit-identical on the GPU, on
+// the host and in the CPU oracle's restatement of the same recipe.
+// MATH = 1 (MI_EDM_MATH_FAST): v_exp_f32 / v_log_f32 hardware transcendentals.
+// Compiled with -ffp-contract=off: nothing fuses unless written as fmaf.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#define MI_HD __host__ __device__ __forceinline__
+
+namespace edm {
+
+template <int MATH>
+MI_HD float expf_(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (MATH == 1) return __expf(x);
+#endif
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return INFINITY;
+    if (x < -103.97208404541015625f) return 0.0f;
+    const float n = rintf(x * 0x1.715476p+0f);
+    float r = fmaf(n, -0x1.62e4p-1f, x);
+    r = fmaf(n, -0x1.7f7d1cp-20f, r);
+    const float z = r * r;
+    float p = 0x1.a0d2bcp-13f;
+    p = fmaf(p, r, 0x1.6e8716p-10f);
+    p = fmaf(p, r, 0x1.1112ep-7f);
+    p = fmaf(p, r, 0x1.5554ep-5f);
+    p = fmaf(p, r, 0x1.555554p-3f);
+    p = fmaf(p, r, 0x1.000002p-1f);
+    p = fmaf(p, z, r);
+    p = p + 1.0f;
+    return ldexpf(p, (int)n);
+}
+
+template <int MATH>
+MI_HD float logf_(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (MATH == 1) return __logf(x);
+#endif
+    if (x != x) return x;
+    if (x < 0.0f) return NAN;
+    if (x == 0.0f) return -INFINITY;
+    if (x == INFINITY) return x;
+    int e;
+    float m = frexpf(x, &e);
+    if (m < 0x1.6a09e6p-1f) { m = m + m; e -= 1; }
+    const float f = m - 1.0f;
+    const float z = f * f;
+    float p = 0x1.203736p-4f;
+    p = fmaf(p, f, -0x1.d7a37p-4f);
+    p = fmaf(p, f, 0x1.de4a34p-4f);
+    p = fmaf(p, f, -0x1.fcba9ap-4f);
+    p = fmaf(p, f, 0x1.23d37ep-3f);
+    p = fmaf(p, f, -0x1.555ca2p-3f);
+    p = fmaf(p, f, 0x1.999a2ep-3f);
+    p = fmaf(p, f, -0x1.fffffep-3f);
+    p = fmaf(p, f, 0x1.555554p-2f);
+    const float fe = (float)e;
+    float y = (p * f) * z;
+    y = fmaf(fe, -0x1.bd0106p-13f, y);
+    y = fmaf(-0.5f, z, y);
+    float r = f + y;
+    r = fmaf(fe, 0x1.63p-1f, r);
+    return r;
+}
+
+template <int MATH>
+MI_HD float powf_(float a, float b)
+{
+    return expf_<MATH>(b * logf_<MATH>(a));
+}
+
+template <int MATH>
+MI_HD float erfinvf_(float x)
+{
+    float w = -logf_<MATH>((1.0f - x) * (1.0f + x));
+    float p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = fmaf(p, w, 3.43273939e-07f);
+        p = fmaf(p, w, -3.5233877e-06f);
+        p = fmaf(p, w, -4.39150654e-06f);
+        p = fmaf(p, w, 0.00021858087f);
+        p = fmaf(p, w, -0.00125372503f);
+        p = fmaf(p, w, -0.00417768164f);
+        p = fmaf(p, w, 0.246640727f);
+        p = fmaf(p, w, 1.50140941f);
+    } else {
+        w = sqrtf(w) - 3.0f;
+        p = -0.000200214257f;
+        p = fmaf(p, w, 0.000100950558f);
+        p = fmaf(p, w, 0.00134934322f);
+        p = fmaf(p, w, -0.00367342844f);
+        p = fmaf(p, w, 0.00573950773f);
+        p = fmaf(p, w, -0.0076224613f);
+        p = fmaf(p, w, 0.00943887047f);
+        p = fmaf(p, w, 1.00167406f);
+        p = fmaf(p, w, 2.83297682f);
+    }
+    return p * x;
+}
+
+MI_HD uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// per-neuron beta: counter-based draw (replaces cuRAND XORWOW seeded by clock(),
+// EventDrivenMap.cu:103-104,179); sigma == 0 -> the mean exactly.
+template <int MATH>
+MI_HD float beta_of(float mean, float sigma, uint64_t seed, uint32_t n_grid, uint64_t r, uint32_t i)
+{
+    if (sigma == 0.0f) return mean;
+    const uint64_t ctr = r * n_grid + i;
+    const uint64_t h = mix64(seed + 0x9E3779B97F4A7C15ull * (ctr + 1));
+    const float u = ((float)(uint32_t)(h >> 40) + 0.5f) * 0x1.0p-24f;
+    const float z = 0x1.6a09e6p+0f * erfinvf_<MATH>(fmaf(2.0f, u, -1.0f));
+    return fmaf(sigma, z, mean);
+}
+
+// model constants handed to the kernels by value
+struct Model {
+    float vth, a1, a2, b1, b2, I, L;
+    float tol_f;          // largest float <= newton_tol: (double)|f| > tol  <=>  |f| > tol_f
+    uint32_t max_iter;
+    uint32_t S, N, R;
+    float T;
+    float beta_mean, beta_sigma;
+    uint64_t seed;
+    uint32_t real_offset;
+};
+
+struct FdF {
+    float f, df;
+};
+
+// fun/dfun, EventDrivenMap.cu:544-552, sharing e1 = exp(-t), e2 = exp((1-beta) t)
+MI_HD FdF fun_dfun_e(const Model& M, float e1, float e2, float v, float s, float beta)
+{
+    const float se = s * e1;
+    FdF r;
+    r.f = ((v * e1 + M.I * (1.0f - e1)) + (se / (1.0f - beta)) * (e2 - 1.0f)) - M.vth;
+    r.df = ((M.I * e1 - v * e1) + se * e2) + (se * (e2 - 1.0f)) / (beta - 1.0f);
+    return r;
+}
+
+// eventTime, EventDrivenMap.cu:554-573.  At t = 0 both exponentials are exactly 1
+// (expf_(+-0) == 1), so the first evaluation needs no exp.
+template <int MATH>
+MI_HD float event_time(const Model& M, float v0, float s0, float beta)
+{
+    const float gap = M.vth - M.I;
+    const float ratio = s0 / gap;
+    const float pw = powf_<MATH>(ratio, 1.0f / beta);
+    const float thr = (M.vth * pw + M.I * (1.0f - pw)) - (gap / (beta - 1.0f)) * (ratio - pw);
+    const bool decision = v0 > thr;
+    float t = 0.0f;
+    FdF r = fun_dfun_e(M, 1.0f, 1.0f, v0, s0, beta);
+    float f = r.f * (decision ? 1.0f : 0.0f), df = r.df;
+    uint32_t counter = 0;
+    while ((fabsf(f) > M.tol_f) && (counter < M.max_iter)) {
+        t = t - f / df;
+        r = fun_dfun_e(M, expf_<MATH>(-t), expf_<MATH>((1.0f - beta) * t), v0, s0, beta);
+        f = r.f;
+        df = r.df;
+        ++counter;
+    }
+    return fabsf(t) + 100.0f * (1.0f - (decision ? 1.0f : 0.0f));
+}
+
+}  // namespace edm

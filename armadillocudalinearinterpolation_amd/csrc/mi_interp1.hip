@@ -225,7 +225,6 @@ mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, const double* xq, double* yq,
 
 // ---- host-side table construction -----------------------------------------
 
-inline int guess_index(double q, double xmin, double scale) { return (int)((q - xmin) * scale); }
 
 mi_status upload(mi_ctx* ctx, void** dev, const void* host, size_t bytes)
 {

@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X interpolation hot path.
+
+Workload (BASELINE.json configs[1]): 1-D linear interpolation of 1e8 random fp64 queries (SplitMix64 seed
+0x5EED0003, U[0,1)) over a 1e6-node table X_i = i/(NG-1), Y_i = sin(2 pi X_i) + 0.5 X_i, through the
+arma::interp1-shaped entry point (explicit X, general table).  One "step" = one pass of
+mi_interp1_f64_dev over the rank's 1e8 resident queries.  Inputs are generated in HBM before timing.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N)
+
+Multi-GPU: the query axis shards trivially: every rank owns its own 1e8-query shard and a
+replica of the table; there is no data-path collective in the timed region ("scaling": "weak").  The optional
+all-gather that reassembles the full result vector on every rank is timed separately (extra.allgather_ms).
+
+Rank 0 prints ONE JSON line (the last line of stdout).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NG = 1_000_000
+NQ = 100_000_000
+SEED_Q = 0x5EED0003
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nq", type=int, default=NQ, help="queries per GPU (default: BASELINE size 1e8)")
+    ap.add_argument("--ng", type=int, default=NG)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (sorted queries, "
+                    "implicit-uniform table, config 3, restrict+mean, all-gather)")
+    ap.add_argument("--table", choices=["general", "uniform"], default="general")
+    ap.add_argument("--queries", choices=["random", "sorted", "uniform"], default="random")
+    return ap.parse_args()
+
+
+def timed_loop(ctx, fn, steps, warmup, barrier):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize; returns
+    (host wall seconds, HIP-event seconds over the same K launches)."""
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    tm = ctx.timer()
+    t0 = time.perf_counter()
+    tm.start()
+    for _ in range(steps):
+        fn()
+    tm.stop()
+    torch.cuda.synchronize()
+    barrier()
+    wall = time.perf_counter() - t0
+    return wall, tm.elapsed_ms() * 1e-3
+
+
+def cpu_baseline(X, Y, nq_total):
+    """The CPU oracle (kind 'port': the repo's restatement of arma::interp1 semantics, bracket formulation,
+    OpenMP over queries) on a bounded sample of the same workload, on this box's host cores."""
+    import oracle
+    threads = min(oracle.max_threads(), os.cpu_count() or 1)
+    n = 20_000_000
+    xi = oracle.splitmix_uniform(SEED_Q, n)
+    oracle.interp1_bracket(X, Y, xi[:1_000_000], nthreads=threads)      # warm caches / thread pool
+    best = None
+    for _ in range(2):
+        t = time.perf_counter()
+        oracle.interp1_bracket(X, Y, xi, nthreads=threads)
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    return {"value": n / best, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": "first %d of the %d SplitMix64 queries (seed 0x5EED0003), same 1e6-node table, "
+                      "oracle.interp1_bracket, best of 2, %.2f s per pass" % (n, nq_total, best)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import armadillocudalinearinterpolation_amd as mi
+    from armadillocudalinearinterpolation_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus,
+              file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU: the hot path has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+        def barrier():
+            dist.barrier()
+    else:
+        def barrier():
+            pass
+
+    ctx = mi.Context(local_rank)              # follows torch's current stream on this device
+    info = ctx.device_info()
+    X, Y = synth.config_grid(args.ng)
+    if args.table == "general":
+        grid = mi.Grid1.from_nodes(ctx, X, Y, sanitise=False)
+    else:
+        grid = mi.Grid1.uniform(ctx, 0.0, 1.0 / (args.ng - 1), Y)
+    ginfo = grid.info()
+    nq = args.nq
+    # each rank's shard of the N*nq-query batch: SplitMix64 stream offset by rank
+    xq = synth.splitmix_uniform(SEED_Q + 0x1000 * rank, nq, dev)
+    if args.queries == "sorted":
+        xq = torch.sort(xq).values
+    elif args.queries == "uniform":
+        xq = torch.arange(nq, dtype=torch.float64, device=dev) / (nq - 1)
+    yq = torch.empty_like(xq)
+    torch.cuda.synchronize()
+
+    wall, ev = timed_loop(ctx, lambda: grid.interp(xq, out=yq), args.steps, args.warmup, barrier)
+    t = torch.tensor([wall, ev], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max, ev_max = float(t[0]), float(t[1])
+
+    alg_bytes = 16.0 * nq + (16.0 if args.table == "general" else 8.0) * args.ng    # per launch, per GPU
+    kernel_s = ev / args.steps                                                        # this rank's avg launch
+    achieved = alg_bytes / kernel_s / 1e9
+    result = {
+        "metric": "interpolated points/sec (fp64)",
+        "value": world * nq * args.steps / wall_max,
+        "unit": "points/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall_max / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "1D linear interp, %.0e %s queries on %.0e-point grid, fp64 (BASELINE configs[1])"
+                        % (nq, args.queries, args.ng),
+            "queries_per_gpu": nq, "grid_nodes": args.ng, "table": args.table,
+            "table_mode": ginfo["mode"], "table_bytes": ginfo["table_bytes"],
+            "entry_point": "mi_interp1_f64_dev", "sharding": "queries/%d, table replicated, no collective" % world,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "kernel": "interp1_vec_kernel<%d,2>" % ginfo["mode"],
+            "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
+            "note": "achieved = (16 B/query + table bytes) / HIP-event time per launch; traffic: see profiles/",
+        },
+        "device": info["name"],
+    }
+
+    extra = {}
+    if rank == 0 and not args.no_extra:
+        reps = max(3, min(args.steps, 10))
+
+        def quick(fn):
+            _, e = timed_loop(ctx, fn, reps, 2, lambda: None)
+            return e / reps
+
+        xs = torch.sort(xq).values
+        gu = mi.Grid1.uniform(ctx, 0.0, 1.0 / (args.ng - 1), Y)
+        for name, g, q in (("general_sorted", grid, xs), ("uniform_random", gu, xq), ("uniform_sorted", gu, xs)):
+            s = quick(lambda: g.interp(q, out=yq))
+            extra[name] = {"ms": s * 1e3, "points_per_s": nq / s, "frac_of_8TBps": 16.0 * nq / s / 1e9 / HBM_PEAK_GBPS}
+        del xs
+        s = quick(lambda: yq.copy_(xq))
+        extra["torch_copy_same_bytes"] = {"ms": s * 1e3, "GBps": 16.0 * nq / s / 1e9}
+        # config 3: 4096^2 table, 1e8 scattered queries
+        n3 = 4096
+        g2 = mi.Grid2.uniform(ctx, 0.0, 1.0 / (n3 - 1), n3, 0.0, 1.0 / (n3 - 1), n3, synth.config3_table(n3, dev))
+        q2 = synth.splitmix_uniform(0x5EED0004, 2 * nq, dev)
+        s = quick(lambda: g2.interp(q2[:nq], q2[nq:], out=yq))
+        b3 = 24.0 * nq + 8.0 * n3 * n3
+        extra["config3_bilinear_4096sq"] = {"ms": s * 1e3, "points_per_s": nq / s, "frac_of_8TBps": b3 / s / 1e9 / HBM_PEAK_GBPS}
+        del q2, g2
+        # config 4's interpolation step: Restrict + masked mean over S=3 x R=1e6
+        S, R = 3, 1_000_000
+        t0 = torch.rand(S * R, device=dev) * 5
+        t1 = torch.rand(S * R, device=dev) + 5
+        i0 = torch.randint(0, 1000, (S * R,), device=dev, dtype=torch.int16)
+        i1 = i0 + 1
+        acc = torch.ones(R, device=dev, dtype=torch.int32)
+        s = quick(lambda: mi.restrict_mean(ctx, t0, i0, t1, i1, acc, 5.0, 3.0, 1024, S))
+        extra["restrict_mean_3x1e6"] = {"ms": s * 1e3, "elements_per_s": S * R / s,
+                                         "GBps": (12.0 * S * R + 4.0 * R) / s / 1e9}
+    if world > 1 and not args.no_extra:
+        full = torch.empty(world * nq, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(full, yq)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = time.perf_counter()
+        dist.all_gather_into_tensor(full, yq)
+        torch.cuda.synchronize()
+        dist.barrier()
+        extra["allgather_ms"] = (time.perf_counter() - t) * 1e3
+        extra["allgather_note"] = "RCCL all-gather of %d x 8e8 B result shards, outside the timed region" % world
+        del full
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(X, Y, nq)
+        else:
+            result["cpu_baseline"] = None
+        result["extra"] = extra
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

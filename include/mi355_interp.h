@@ -183,6 +183,9 @@ typedef struct mi_edm_params {
     uint64_t seed;                     /* mSeed                                  */
     int math_mode;                     /* MI_EDM_MATH_EXACT or MI_EDM_MATH_FAST  */
     int mean_quirk;                    /* reproduce the accept[0] clobber        */
+    uint32_t real_offset;              /* global index of this shard's first
+                                          realisation (multi-GPU sharding; only
+                                          enters the per-neuron beta draw)       */
 } mi_edm_params;
 #define MI_EDM_MATH_EXACT 0   /* software exp/log, bit-identical to oracle/edm_oracle.c */
 #define MI_EDM_MATH_FAST  1   /* v_exp_f32 / v_log_f32 hardware transcendentals          */
@@ -210,6 +213,12 @@ mi_status mi_edm_debug_read(mi_edm* e, float* v, float* s, float* w, float* t0, 
 /* duration of the stages of the last compute_f in ms (HIP events):
  * [0] lift, [1] evolve, [2] restrict+mean, [3] whole call */
 mi_status mi_edm_last_timings(mi_edm* e, float ms[4]);
+
+/* Test hook: evaluate the device math routines of the pipeline on arrays
+ * (op: 0 exp, 1 log, 2 pow(a,b), 3 erfinv) so that tests can compare them with
+ * oracle/edm_oracle.c bit for bit.  Device pointers; b_dev may be NULL. */
+mi_status mi_edm_math_probe(mi_ctx* ctx, int math_mode, int op, const float* a_dev, const float* b_dev,
+                            float* out_dev, size_t n);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,7 @@ typedef struct orc_edm_params {
     uint64_t seed;
     int math_mode;
     int mean_quirk;
+    uint32_t real_offset;
 } orc_edm_params;
 
 #define ORC_MAX_SPIKES 8
@@ -161,7 +162,7 @@ float orc_edm_erfinvf(float x)
 float orc_edm_beta(const orc_edm_params* P, uint32_t r, uint32_t i)
 {
     if (P->beta_stddev == 0.0f) return P->beta_mean;
-    const uint64_t ctr = (uint64_t)r * P->n_grid + i;
+    const uint64_t ctr = ((uint64_t)r + P->real_offset) * P->n_grid + i;
     const uint64_t h = orc_mix64(P->seed + 0x9E3779B97F4A7C15ull * (ctr + 1));
     const float u = ((float)(uint32_t)(h >> 40) + 0.5f) * 0x1.0p-24f;      /* (0,1), 24 bits */
     const float z = 0x1.6a09e6p+0f * orc_edm_erfinvf(fmaf(2.0f, u, -1.0f)); /* sqrt(2)*erfinv */
@@ -468,5 +469,5 @@ void orc_edm_default_params(orc_edm_params* p)
     p->vth = 1.0f; p->a1 = 11.0f; p->a2 = 7.0f; p->b1 = 5.0f; p->b2 = 3.5f; p->I = 0.9f; p->L = 3.0f;
     p->newton_tol = 1e-6; p->newton_max_iter = 100; p->n_spikes = 3; p->time_horizon = 5.0f;
     p->n_grid = 1024; p->n_real = 1000; p->beta_mean = 13.0589f; p->beta_stddev = 0.0f;
-    p->seed = 0x5EED0005ull; p->math_mode = 0; p->mean_quirk = 0;
+    p->seed = 0x5EED0005ull; p->math_mode = 0; p->mean_quirk = 0; p->real_offset = 0;
 }

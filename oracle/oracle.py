@@ -145,3 +145,115 @@ def masked_mean_f32(x, accept, nspikes, quirk=False):
     cnt = C.c_uint32(0)
     lib().orc_masked_mean_f32(x, accept, nreal, nspikes, int(bool(quirk)), mean, C.byref(cnt))
     return mean, int(cnt.value)
+
+
+# ---- EventDrivenMap pipeline (oracle/edm_oracle.c) --------------------------------------------
+
+class EdmParams(C.Structure):
+    """orc_edm_params: same field order as mi_edm_params."""
+    _fields_ = [
+        ("vth", C.c_float), ("a1", C.c_float), ("a2", C.c_float), ("b1", C.c_float), ("b2", C.c_float),
+        ("I", C.c_float), ("L", C.c_float),
+        ("newton_tol", C.c_double),
+        ("newton_max_iter", C.c_uint32),
+        ("n_spikes", C.c_uint32),
+        ("time_horizon", C.c_float),
+        ("n_grid", C.c_uint32),
+        ("n_real", C.c_uint32),
+        ("beta_mean", C.c_float),
+        ("beta_stddev", C.c_float),
+        ("seed", C.c_uint64),
+        ("math_mode", C.c_int),
+        ("mean_quirk", C.c_int),
+        ("real_offset", C.c_uint32),
+    ]
+
+
+def _edm_lib():
+    L = lib()
+    if not getattr(L, "_edm_ready", False):
+        pp = C.POINTER(EdmParams)
+        vp = C.c_void_p
+        L.orc_edm_default_params.argtypes = [pp]
+        L.orc_edm_default_params.restype = None
+        L.orc_edm_compute_f.argtypes = [pp, _f64p, _f64p, _u16p] + [vp] * 10 + [C.c_int]
+        L.orc_edm_compute_f.restype = C.c_int
+        L.orc_edm_math_probe.argtypes = [C.c_int, _f32p, _f32p, _f32p, C.c_size_t]
+        L.orc_edm_math_probe.restype = None
+        L.orc_edm_coupling.argtypes = [pp, _f32p]
+        L.orc_edm_coupling.restype = None
+        L.orc_edm_lift.argtypes = [pp, _f32p, _f32p, _f32p]
+        L.orc_edm_lift.restype = None
+        L.orc_edm_seed_indices.argtypes = [pp, _f64p, _u16p]
+        L.orc_edm_seed_indices.restype = None
+        L.orc_edm_event_time.argtypes = [pp, C.c_float, C.c_float, C.c_float]
+        L.orc_edm_event_time.restype = C.c_float
+        L.orc_edm_beta.argtypes = [pp, C.c_uint32, C.c_uint32]
+        L.orc_edm_beta.restype = C.c_float
+        L._edm_ready = True
+    return L
+
+
+def edm_default_params(**overrides):
+    p = EdmParams()
+    _edm_lib().orc_edm_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def edm_math_probe(op, a, b=None):
+    """op: 0 exp, 1 log, 2 pow(a,b), 3 erfinv."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(a if b is None else b, dtype=np.float32)
+    out = np.empty_like(a)
+    _edm_lib().orc_edm_math_probe(int(op), a, b, out, a.size)
+    return out
+
+
+def edm_coupling(p):
+    w = np.empty(p.n_grid, dtype=np.float32)
+    _edm_lib().orc_edm_coupling(C.byref(p), w)
+    return w
+
+
+def edm_lift(p, U):
+    U = np.ascontiguousarray(U, dtype=np.float32)
+    v = np.empty(p.n_grid, dtype=np.float32)
+    s = np.empty(p.n_grid, dtype=np.float32)
+    _edm_lib().orc_edm_lift(C.byref(p), U, v, s)
+    return v, s
+
+
+def edm_seed_indices(p, Z, prev=None):
+    ind = np.zeros(p.n_spikes, dtype=np.uint16) if prev is None else np.array(prev, dtype=np.uint16)
+    _edm_lib().orc_edm_seed_indices(C.byref(p), _c64(Z), ind)
+    return ind
+
+
+def edm_beta(p, r, i):
+    return float(_edm_lib().orc_edm_beta(C.byref(p), int(r), int(i)))
+
+
+def edm_compute_f(p, Z, seed_ind=None, nthreads=1, debug=True):
+    """Whole residual.  Returns (f, dbg) with dbg holding every stage output."""
+    Z = _c64(Z)
+    S, R, N = p.n_spikes, p.n_real, p.n_grid
+    f = np.empty(S, dtype=np.float64)
+    ind = np.zeros(S, dtype=np.uint16) if seed_ind is None else np.array(seed_ind, dtype=np.uint16)
+    dbg = {
+        "v": np.empty(N, np.float32), "s": np.empty(N, np.float32), "w": np.empty(N, np.float32),
+        "t0": np.empty(S * R, np.float32), "i0": np.empty(S * R, np.uint16),
+        "t1": np.empty(S * R, np.float32), "i1": np.empty(S * R, np.uint16),
+        "accept": np.empty(R, np.uint32), "restricted": np.empty(S * R, np.float32),
+        "sums": np.empty(S + 1, np.float64),
+    }
+    order = ["v", "s", "w", "t0", "i0", "t1", "i1", "accept", "restricted", "sums"]
+    ptrs = [C.c_void_p(dbg[k].ctypes.data) if debug else None for k in order]
+    rc = _edm_lib().orc_edm_compute_f(C.byref(p), Z, f, ind, *ptrs, int(nthreads))
+    if rc != 0:
+        raise ValueError("orc_edm_compute_f failed (%d)" % rc)
+    dbg["seed_ind"] = ind
+    return f, dbg

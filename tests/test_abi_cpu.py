@@ -1,0 +1,62 @@
+"""CPU suite: the C-ABI library builds for gfx950, loads, exports every symbol include/mi355_interp.h
+declares, and fails loudly (no CPU fallback) when no GPU is present.  No compute calls here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from armadillocudalinearinterpolation_amd import _build, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mi355_interp.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^\s*(?:mi_status|const char\*|int|void)\s+(mi_[a-z0-9_]+)\s*\(", text, flags=re.M)
+    assert len(names) > 25
+    return sorted(set(names))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = _build.build_lib()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, "declared in mi355_interp.h but not exported: %s" % missing
+    assert lib.mi_abi_version() == 1
+
+
+def test_python_binding_table_matches_header():
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+    _lib.load()            # strict: raises if any symbol is absent
+
+
+def test_code_object_is_gfx950_only():
+    out = subprocess.run(["strings", "-a", _build.LIB_PATH], capture_output=True, text=True).stdout
+    archs = set(re.findall(r"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", out))
+    assert archs == {"gfx950"}, archs
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu suite")
+    import armadillocudalinearinterpolation_amd as mi
+    with pytest.raises(mi.MiError) as e:
+        mi.Context(0)
+    assert e.value.code == 5 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "armadillocudalinearinterpolation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert not re.search(r'#include\s*[<"][^>"]*oracle', src), f
+                assert "liboracle" not in src, f

@@ -1,0 +1,128 @@
+"""GPU parity suite for the EventDrivenMap residual (lift -> evolve -> restrict -> average) through the C ABI.
+EXACT math mode must reproduce oracle/edm_oracle.c BIT FOR BIT at every stage tap (the reference's Save*
+debug dumps, EventDrivenMap.cu:406-503); FAST mode (hardware exp/log) within stated tolerances."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+Z_DRIVER = [0.3310, 0.6914, 1.3557]
+
+
+def _probe(ctx, mode, op, a, b=None):
+    import torch
+    from armadillocudalinearinterpolation_amd import _lib
+    L = _lib.load()
+    ta = torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    tb = torch.from_numpy(np.ascontiguousarray(a if b is None else b, np.float32)).cuda()
+    out = torch.empty_like(ta)
+    _lib.check(L.mi_edm_math_probe(ctx._h, mode, op, C.c_void_p(ta.data_ptr()), C.c_void_p(tb.data_ptr()),
+                                   C.c_void_p(out.data_ptr()), ta.numel()), ctx._h)
+    return out.cpu().numpy()
+
+
+def test_device_math_bit_identical_to_oracle(mi_ctx):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([np.linspace(-110, 95, 300001), rng.standard_normal(200000) * 20,
+                        [0.0, -0.0, np.inf, -np.inf, np.nan, 88.72284, -103.9, -87.4, 1e-30, -1e-30]]).astype(np.float32)
+    assert np.array_equal(_probe(mi_ctx, 0, 0, x), oracle.edm_math_probe(0, x), equal_nan=True)      # exp, incl. subnormal results
+    xl = np.concatenate([np.exp(rng.uniform(-100, 88, 400000)), [0.0, -1.0, np.inf, np.nan, 1e-42, 1.0]]).astype(np.float32)
+    assert np.array_equal(_probe(mi_ctx, 0, 1, xl), oracle.edm_math_probe(1, xl), equal_nan=True)    # log, incl. subnormal inputs
+    a = np.concatenate([rng.uniform(-5, 400, 200000), [0.0, -0.0]]).astype(np.float32)
+    b = rng.uniform(0.02, 0.2, a.size).astype(np.float32)
+    assert np.array_equal(_probe(mi_ctx, 0, 2, a, b), oracle.edm_math_probe(2, a, b), equal_nan=True)
+    u = rng.uniform(-1, 1, 200000).astype(np.float32)
+    assert np.array_equal(_probe(mi_ctx, 0, 3, u), oracle.edm_math_probe(3, u), equal_nan=True)
+    # FAST mode: hardware transcendentals, a few ulp
+    xs = np.linspace(-60, 60, 100001).astype(np.float32)
+    fast = _probe(mi_ctx, 1, 0, xs).astype(np.float64)
+    assert np.max(np.abs(fast - np.exp(xs.astype(np.float64))) / np.exp(xs.astype(np.float64))) < 2e-5
+
+
+def _run(mi_ctx, **kw):
+    import armadillocudalinearinterpolation_amd as mi
+    R = kw.pop("n_real", 8)
+    edm = mi.EventDrivenMap(mi_ctx, [13.0589], R, **kw)
+    f, partial = edm.ComputeF(Z_DRIVER, want_partial=True)
+    return edm, f, partial, edm.debug_read()
+
+
+@pytest.mark.parametrize("n_grid,n_real", [(1024, 8), (512, 5), (1000, 3), (64, 4)])
+def test_compute_f_exact_mode_bit_parity(mi_ctx, n_grid, n_real):
+    edm, f, partial, dbg = _run(mi_ctx, n_grid=n_grid, n_real=n_real)
+    p = oracle.edm_default_params(n_grid=n_grid, n_real=n_real)
+    fo, d = oracle.edm_compute_f(p, Z_DRIVER, nthreads=8)
+    assert np.array_equal(dbg["seed_ind"], d["seed_ind"])
+    for k in ("w", "v", "s"):
+        assert np.array_equal(dbg[k], d[k], equal_nan=True), k           # coupling table + lift profile
+    for k in ("t0", "i0", "t1", "i1", "accept"):
+        assert np.array_equal(dbg[k], d[k], equal_nan=True), k           # evolve: last / crossed events
+    assert np.array_equal(dbg["restricted"], d["restricted"], equal_nan=True)
+    assert partial[-1] == d["sums"][-1]
+    assert np.allclose(partial[:-1], d["sums"][:-1], rtol=1e-12, atol=0, equal_nan=True)
+    assert np.allclose(f, fo, rtol=0, atol=2e-7, equal_nan=True)         # 1 ulp(fp32) of the mean (sum order)
+    # residual recomputed from the partial sums (what a multi-GPU all-reduce feeds) equals the device path
+    assert np.allclose(edm.residual_from_sums(Z_DRIVER, partial), f, rtol=0, atol=1e-15, equal_nan=True)
+
+
+def test_compute_f_heterogeneous_beta_bit_parity(mi_ctx):
+    kw = dict(n_grid=512, n_real=6, beta_stddev=0.4, seed=987654321)
+    edm, f, partial, dbg = _run(mi_ctx, **kw)
+    p = oracle.edm_default_params(**kw)
+    fo, d = oracle.edm_compute_f(p, Z_DRIVER, nthreads=8)
+    for k in ("t0", "i0", "t1", "i1", "accept", "restricted"):
+        assert np.array_equal(dbg[k], d[k], equal_nan=True), k
+    assert len(set(dbg["t0"][:6].tolist())) > 1                          # realisations really differ
+    assert np.allclose(f, fo, rtol=0, atol=2e-7, equal_nan=True)
+
+
+def test_setters_and_second_call(mi_ctx):
+    """SetNoThreads(512) then ComputeF (Driver.cu:69-71) and a perturbed Z (finite-difference column)."""
+    import armadillocudalinearinterpolation_amd as mi
+    edm = mi.EventDrivenMap(mi_ctx, [13.0589], 4)
+    f1024 = edm.ComputeF(Z_DRIVER)
+    edm.SetNoThreads(512)
+    f512 = edm.ComputeF(Z_DRIVER)
+    p = oracle.edm_default_params(n_grid=512, n_real=4)
+    fo, _ = oracle.edm_compute_f(p, Z_DRIVER, nthreads=4)
+    assert np.allclose(f512, fo, rtol=0, atol=2e-7)
+    assert not np.array_equal(f1024, f512)
+    Zp = [Z_DRIVER[0] + 1e-2, Z_DRIVER[1], Z_DRIVER[2]]                  # NewtonSolver.cpp:184-191, eps = 1e-2
+    fp = edm.ComputeF(Zp)
+    fpo, _ = oracle.edm_compute_f(p, Zp, nthreads=4)
+    assert np.allclose(fp, fpo, rtol=0, atol=2e-7)
+    edm.SetTimeHorizon(4.0)
+    p.time_horizon = 4.0
+    ft, _ = oracle.edm_compute_f(p, Z_DRIVER, nthreads=4)
+    assert np.allclose(edm.ComputeF(Z_DRIVER), ft, rtol=0, atol=2e-7)
+    with pytest.raises(mi.MiError):
+        mi.EventDrivenMap(mi_ctx, [13.0589], 4, n_grid=2048)
+
+
+def test_fast_mode_within_tolerance(mi_ctx):
+    import armadillocudalinearinterpolation_amd as mi
+    _, f, _, dbg = _run(mi_ctx, n_real=4, math_mode=mi.MATH_FAST)
+    p = oracle.edm_default_params(n_real=4)
+    fo, d = oracle.edm_compute_f(p, Z_DRIVER, nthreads=4)
+    assert np.all(dbg["accept"] == 1)
+    assert np.max(np.abs(dbg["i0"].astype(int) - d["i0"].astype(int))) <= 1
+    assert np.max(np.abs(dbg["restricted"] - d["restricted"])) < 5e-3      # positions: < 1 grid cell (5.9e-3)
+    assert np.max(np.abs(f - fo)) < 5e-3
+
+
+def test_many_realisations_are_identical_when_sigma_is_zero(mi_ctx):
+    """R = 20000 (grid-stride path, > resident waves): sigma = 0 => every realisation equals realisation 0."""
+    edm, f, partial, dbg = _run(mi_ctx, n_grid=512, n_real=20000)
+    for k in ("t0", "i0", "t1", "i1"):
+        a = dbg[k].reshape(3, 20000)
+        assert np.all(a == a[:, :1]), k
+    assert np.all(dbg["accept"] == dbg["accept"][0])
+    p = oracle.edm_default_params(n_grid=512, n_real=2)
+    fo, d = oracle.edm_compute_f(p, Z_DRIVER)
+    assert np.array_equal(dbg["t0"].reshape(3, 20000)[:, 0], d["t0"].reshape(3, 2)[:, 0])
+    t = edm.last_timings()
+    assert t["evolve_ms"] > 0 and t["total_ms"] >= t["evolve_ms"]

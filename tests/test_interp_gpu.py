@@ -1,0 +1,266 @@
+"""GPU parity suite for the interpolation hot path: libmi355interp.so (through the C ABI) against the CPU
+oracle on the same inputs, against the committed golden vectors, and -- at BASELINE.json's full size --
+through size-independent properties.  Bar: fp64 results BIT-EXACT (same formula, no FMA contraction on
+either side), which is stricter than the 1e-12 relative tolerance north_star states."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    import torch
+    if a.dtype == np.uint16:
+        a = a.view(np.int16)
+    elif a.dtype == np.uint32:
+        a = a.view(np.int32)
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _eq(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+# ---------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize("tag", ["uniform", "random"])
+def test_config1_golden(mi_ctx, golden_dir, tag):
+    import armadillocudalinearinterpolation_amd as mi
+    g = _load(golden_dir, "interp1_config1_%s.npz" % tag)
+    ng, nq = int(g["ng"]), int(g["nq"])
+    X = np.arange(ng) / (ng - 1)
+    Y = np.sin(2 * np.pi * X) + 0.5 * X
+    xi = np.arange(nq) / (nq - 1) if tag == "uniform" else oracle.splitmix_uniform(int(g["seed"]), nq)
+    grid = mi.Grid1.from_nodes(mi_ctx, X, Y)
+    out = grid.interp(_t(xi)).cpu().numpy()
+    assert _eq(out[g["sample_idx"]], g["sample_yi"])
+    assert hashlib.sha256(out.tobytes()).hexdigest() == str(g["sha256_full"])
+    # host convenience entry points (what the arma::vec wrapper calls)
+    assert _eq(grid.interp_host(xi), out)
+    assert _eq(mi.interp1(mi_ctx, X, Y, xi), out)
+
+
+@pytest.mark.parametrize("name,mode", [("interp1_nonuniform.npz", 1), ("interp1_clustered.npz", 2)])
+def test_general_grid_golden(mi_ctx, golden_dir, name, mode):
+    import armadillocudalinearinterpolation_amd as mi
+    g = _load(golden_dir, name)
+    grid = mi.Grid1.from_nodes(mi_ctx, g["X"], g["Y"])
+    assert grid.info()["mode"] == mode
+    assert _eq(grid.interp(_t(g["XI"])).cpu().numpy(), g["YI"])
+    assert _eq(grid.interp(_t(g["XI"]), extrap=-7.5).cpu().numpy(),
+               oracle.interp1_bracket(g["X"], g["Y"], g["XI"], extrap=-7.5))
+    if "X_shuffled_dup" in g.files:
+        assert _eq(mi.interp1(mi_ctx, g["X_shuffled_dup"], g["Y_shuffled_dup"], g["XI"]), g["YI"])
+
+
+def test_bilinear_golden(mi_ctx, golden_dir):
+    import armadillocudalinearinterpolation_amd as mi
+    g = _load(golden_dir, "interp2_bilinear.npz")
+    grid = mi.Grid2.from_axes(mi_ctx, g["xg"], g["yg"], g["Z"])
+    assert _eq(grid.interp(_t(g["XQ"]), _t(g["YQ"])).cpu().numpy(), g["ZQ"])
+    assert _eq(grid.interp_host(g["XQ"], g["YQ"]), g["ZQ"])
+    nx, ny = g["xg"].size, g["yg"].size
+    gu = mi.Grid2.uniform(mi_ctx, 0.0, 1.0 / (nx - 1), nx, 0.0, 1.0 / (ny - 1), ny, g["Z"])
+    ref = oracle.interp2_bilinear_uniform(0.0, 1.0 / (nx - 1), nx, 0.0, 1.0 / (ny - 1), ny, g["Z"], g["XQ"], g["YQ"])
+    assert _eq(gu.interp(_t(g["XQ"]), _t(g["YQ"])).cpu().numpy(), ref)
+
+
+def test_restrict_and_mean_golden(mi_ctx, golden_dir):
+    import armadillocudalinearinterpolation_amd as mi
+    g = _load(golden_dir, "restrict_3x1000.npz")
+    T, L, N = float(g["T"]), float(g["L"]), int(g["N"])
+    t0, i0, t1, i1, acc = _t(g["t0"]), _t(g["i0"]), _t(g["t1"]), _t(g["i1"]), _t(g["accept"])
+    out = mi.restrict(mi_ctx, t0, i0, t1, i1, T, L, N)
+    assert np.array_equal(out.cpu().numpy(), g["out"])                       # bit-exact fp32
+    for quirk, key in ((False, "mean"), (True, "mean_quirk")):
+        m, c = mi.masked_mean(mi_ctx, out, acc, 3, quirk=quirk)
+        f = mi.restrict_mean(mi_ctx, t0, i0, t1, i1, acc, T, L, N, 3, quirk=quirk, want_restricted=True, want_sums=True)
+        for got in (m.cpu().numpy(), f["mean"].cpu().numpy()):
+            # fp64 partial sums are added in a different order than the oracle's index order:
+            # tolerance 1 ulp of fp32 (see oracle/interp_oracle.c orc_masked_mean_f32)
+            assert np.all(np.abs(got - g[key]) <= np.spacing(np.abs(g[key]).astype(np.float32)))
+        assert int(c.item()) == int(g["count"]) == int(f["count"].item())
+        assert np.array_equal(f["restricted"].cpu().numpy(), g["out"])
+        assert np.allclose(f["sums"].cpu().numpy() / int(g["count"]), g[key], rtol=1e-6)
+    # in-place form of the reference (out aliases lastSpikeTime, EventDrivenMap.cu:783)
+    t0c = t0.clone()
+    mi.restrict(mi_ctx, t0c, i0, t1, i1, T, L, N, out=t0c)
+    assert np.array_equal(t0c.cpu().numpy(), g["out"])
+    # SURVEY 8c known answer, exact in fp32
+    kat = mi.restrict(mi_ctx, _t(np.float32([4])), _t(np.uint16([512])), _t(np.float32([6])), _t(np.uint16([514])),
+                      5.0, 3.0, 1024)
+    assert kat.cpu().numpy()[0] == np.float32(0.005859375)
+
+
+# ---------------------------------------------------------------- seeded parity vs the oracle
+@pytest.mark.parametrize("nq", [0, 1, 2, 3, 255, 256, 257, 1023, 100003])
+def test_ragged_sizes_all_modes(mi_ctx, nq):
+    import armadillocudalinearinterpolation_amd as mi
+    import torch
+    ng = 4097
+    u = oracle.splitmix_uniform(1234, ng)
+    grids = {
+        "uniformX": (np.arange(ng) / (ng - 1), 1),
+        "jitterX": ((np.arange(ng) + 0.5 * u) / ng, 1),
+        "clustered": (np.unique(np.sort(u ** 5)), 2),
+    }
+    q = oracle.splitmix_uniform(4321 + nq, nq) * 1.1 - 0.05
+    if nq > 8:
+        q[:4] = [np.nan, -1.0, 2.0, 0.0]
+    for name, (X, mode) in grids.items():
+        Y = np.sin(9 * X) + X
+        grid = mi.Grid1.from_nodes(mi_ctx, X, Y)
+        assert grid.info()["mode"] == mode, name
+        ref = oracle.interp1_bracket(X, Y, q)
+        assert _eq(grid.interp(_t(q)).cpu().numpy(), ref), name
+        if nq > 3:   # misaligned (8-byte but not 16-byte aligned) query / result pointers -> scalar kernel
+            buf = _t(np.concatenate([[0.0], q]))
+            out = torch.zeros(nq + 1, dtype=torch.float64, device="cuda:0")
+            grid.interp(buf[1:], out=out[1:])
+            assert _eq(out[1:].cpu().numpy(), ref), name
+    # implicit uniform table
+    ng2, x0, dx = 3000, -1.25, 1.0 / 2999
+    Y = np.cos(np.arange(ng2) * 0.01)
+    gu = mi.Grid1.uniform(mi_ctx, x0, dx, Y)
+    qu = q * 1.2 + x0
+    assert _eq(gu.interp(_t(qu)).cpu().numpy(), oracle.interp1_uniform(x0, dx, Y, qu))
+
+
+def test_queries_on_nodes_and_cell_midpoints(mi_ctx):
+    import armadillocudalinearinterpolation_amd as mi
+    rng = np.random.default_rng(8)
+    X = np.cumsum(rng.random(5000) + 1e-6)
+    Y = rng.standard_normal(5000)
+    grid = mi.Grid1.from_nodes(mi_ctx, X, Y)
+    assert np.array_equal(grid.interp(_t(X.copy())).cpu().numpy(), Y)            # exact at every node
+    mid = 0.5 * (X[:-1] + X[1:])
+    assert _eq(grid.interp(_t(mid)).cpu().numpy(), oracle.interp1_bracket(X, Y, mid))
+    nxt = np.nextafter(X, np.inf)[:-1]                                            # one ulp right of each node
+    prv = np.nextafter(X, -np.inf)[1:]
+    for q in (nxt, prv):
+        assert _eq(grid.interp(_t(q)).cpu().numpy(), oracle.interp1_bracket(X, Y, q))
+
+
+def test_grid_validation_errors(mi_ctx):
+    import armadillocudalinearinterpolation_amd as mi
+    with pytest.raises(mi.MiError) as e:
+        mi.Grid1.from_nodes(mi_ctx, [0.0, 2.0, 1.0], [0.0, 1.0, 2.0], sanitise=False)
+    assert e.value.code == 2
+    with pytest.raises(mi.MiError):
+        mi.Grid1.from_nodes(mi_ctx, [1.0, 1.0], [0.0, 1.0])          # < 2 unique nodes
+    with pytest.raises(mi.MiError):
+        mi.Grid1.from_nodes(mi_ctx, [0.0, np.nan, 1.0], [0.0, 1.0, 2.0])
+    with pytest.raises(mi.MiError):
+        mi.Grid1.uniform(mi_ctx, 0.0, -1.0, [0.0, 1.0])
+    with pytest.raises(ValueError):
+        mi.Grid1.from_nodes(mi_ctx, [0.0, 1.0], [0.0, 1.0, 2.0])
+
+
+def test_scattered_bilinear_seeded(mi_ctx):
+    import armadillocudalinearinterpolation_amd as mi
+    nx, ny, nq = 257, 129, 200001
+    xg = np.cumsum(oracle.splitmix_uniform(1, nx) + 0.01)
+    yg = np.cumsum(oracle.splitmix_uniform(2, ny) ** 3 + 1e-4)          # y axis: binary-search path
+    Z = np.sin(xg)[None, :] * np.cos(3 * yg)[:, None]
+    q = oracle.splitmix_uniform(3, 2 * nq)
+    xq = q[:nq] * (xg[-1] - xg[0]) * 1.02 + xg[0] - 0.01
+    yq = q[nq:] * (yg[-1] - yg[0]) * 1.02 + yg[0] - 0.001
+    xq[:5] = [xg[0], xg[-1], xg[10], xg[-1], np.nan]
+    yq[:5] = [yg[0], yg[-1], yg[-1], yg[3], yg[1]]
+    grid = mi.Grid2.from_axes(mi_ctx, xg, yg, Z)
+    assert _eq(grid.interp(_t(xq), _t(yq)).cpu().numpy(), oracle.interp2_bilinear(xg, yg, Z, xq, yq, nthreads=4))
+
+
+# ---------------------------------------------------------------- BASELINE-size property tests
+def test_config2_full_size_properties(mi_ctx):
+    """1e8 random queries over a 1e6-node table (BASELINE.json configs[1]): properties + sampled parity."""
+    import armadillocudalinearinterpolation_amd as mi
+    import torch
+    NG, NQ = 10**6, 10**8
+    X = np.arange(NG) / (NG - 1)
+    Y = np.sin(2 * np.pi * X) + 0.5 * X
+    grid = mi.Grid1.from_nodes(mi_ctx, X, Y, sanitise=False)
+    g = torch.Generator(device="cuda:0").manual_seed(0x5EED0003)
+    xq = torch.rand(NQ, dtype=torch.float64, device="cuda:0", generator=g)
+    out = grid.interp(xq)
+    # sampled bit parity with the oracle (2e5 queries spread over the vector)
+    idx = torch.arange(0, NQ, NQ // 200000, device="cuda:0")
+    ref = oracle.interp1_bracket(X, Y, xq[idx].cpu().numpy(), nthreads=8)
+    assert np.array_equal(out[idx].cpu().numpy(), ref)
+    # shard-and-concatenate equals whole (two unequal shards, second one starting at an odd offset)
+    cut = 33_333_333
+    out2 = torch.empty_like(out)
+    grid.interp(xq[:cut].contiguous(), out=out2[:cut])
+    grid.interp(xq[cut:].contiguous(), out=out2[cut:])
+    assert torch.equal(out, out2)
+    # monotone table on [0, 0.2] (Y' > 0 there): sorted queries give sorted results
+    sub = torch.sort(xq[:10_000_000] * 0.2).values
+    r = grid.interp(sub)
+    assert bool((r[1:] >= r[:-1]).all())
+    # affine table: reproduced to a few ulp at every one of the 1e8 points
+    ga = mi.Grid1.from_nodes(mi_ctx, X, 3.0 * X - 1.0, sanitise=False)
+    ra = ga.interp(xq)
+    assert float((ra - (3.0 * xq - 1.0)).abs().max()) <= 1e-15
+    # implicit-uniform table on a power-of-two step grid is bitwise equal to the explicit table
+    NP = 2**20 + 1
+    Xp = np.arange(NP) * 2.0 ** -20
+    Yp = np.cos(5 * Xp)
+    a = mi.Grid1.from_nodes(mi_ctx, Xp, Yp, sanitise=False).interp(xq)
+    b = mi.Grid1.uniform(mi_ctx, 0.0, 2.0 ** -20, Yp).interp(xq)
+    assert torch.equal(a, b)
+
+
+def test_config3_full_grid_sampled(mi_ctx):
+    """4096x4096 table (BASELINE.json configs[2]), 2e7 scattered queries: sampled parity + bilinear exactness."""
+    import armadillocudalinearinterpolation_amd as mi
+    import torch
+    n = 4096
+    ax = np.arange(n) / (n - 1)
+    Z = np.sin(2 * np.pi * ax)[:, None] * np.cos(2 * np.pi * ax)[None, :] + ax[None, :] * ax[:, None]
+    grid = mi.Grid2.uniform(mi_ctx, 0.0, 1.0 / (n - 1), n, 0.0, 1.0 / (n - 1), n, Z)
+    g = torch.Generator(device="cuda:0").manual_seed(0x5EED0004)
+    NQ = 20_000_000
+    xq = torch.rand(NQ, dtype=torch.float64, device="cuda:0", generator=g)
+    yq = torch.rand(NQ, dtype=torch.float64, device="cuda:0", generator=g)
+    out = grid.interp(xq, yq)
+    idx = torch.arange(0, NQ, 100, device="cuda:0")
+    ref = oracle.interp2_bilinear_uniform(0.0, 1.0 / (n - 1), n, 0.0, 1.0 / (n - 1), n, Z,
+                                          xq[idx].cpu().numpy(), yq[idx].cpu().numpy(), nthreads=8)
+    assert np.array_equal(out[idx].cpu().numpy(), ref)
+    # a bilinear function is reproduced to rounding everywhere
+    Zb = 2.0 * ax[None, :] - ax[:, None] + 0.5 * ax[None, :] * ax[:, None] + 1.0
+    gb = mi.Grid2.uniform(mi_ctx, 0.0, 1.0 / (n - 1), n, 0.0, 1.0 / (n - 1), n, Zb)
+    rb = gb.interp(xq, yq)
+    assert float((rb - (2.0 * xq - yq + 0.5 * xq * yq + 1.0)).abs().max()) < 1e-14
+
+
+def test_restrict_mean_cfg4_size(mi_ctx):
+    """S=3 x R=1e6 (BASELINE config 4's interpolation step): fused kernel == separate kernels == oracle."""
+    import armadillocudalinearinterpolation_amd as mi
+    S, R, N = 3, 1_000_000, 1024
+    rng = np.random.default_rng(4)
+    t0 = (rng.random(S * R) * 5).astype(np.float32)
+    t1 = (5 + rng.random(S * R)).astype(np.float32)
+    i0 = rng.integers(0, N - 2, S * R).astype(np.uint16)
+    i1 = (i0 + 1).astype(np.uint16)
+    acc = (rng.random(R) < 0.97).astype(np.uint32)
+    ref = oracle.restrict_f32(t0, i0, t1, i1, 5.0, 3.0, N)
+    mref, cref = oracle.masked_mean_f32(ref, acc, S)
+    d = [_t(a) for a in (t0, i0, t1, i1, acc)]
+    out = mi.restrict(mi_ctx, d[0], d[1], d[2], d[3], 5.0, 3.0, N)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    f = mi.restrict_mean(mi_ctx, *d, 5.0, 3.0, N, S, want_restricted=True)
+    assert np.array_equal(f["restricted"].cpu().numpy(), ref)
+    assert int(f["count"].item()) == cref
+    assert np.all(np.abs(f["mean"].cpu().numpy() - mref) <= np.spacing(np.abs(mref)))
+    # run-to-run reproducibility (no float atomics)
+    f2 = mi.restrict_mean(mi_ctx, *d, 5.0, 3.0, N, S)
+    assert np.array_equal(f["mean"].cpu().numpy(), f2["mean"].cpu().numpy())
