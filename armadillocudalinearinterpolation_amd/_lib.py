@@ -98,6 +98,13 @@ def load(build_if_missing=True, strict=True):
         if not build_if_missing:
             raise RuntimeError("%s is missing: run __graft_entry__.build() (no CPU fallback exists)" % path)
         _build.build_lib()
+    # PyTorch wheels bundle their own libamdhip64; two HIP runtimes in one process cannot both own the
+    # device ("No HIP GPUs are available").  Import torch first so that libmi355interp.so binds to the
+    # runtime torch already loaded (same SONAME) and streams/pointers are shared.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     missing = []
     for name, (res, args) in SIGNATURES.items():

@@ -8,7 +8,18 @@
 //
 // Table layouts (all with one padding node so that node l+1 is always
 // readable):
-//   mode 0  implicit uniform   y[n+1]                 8 B/node, X_i = fma(i,dx,x0)
+//   mode 0  implicit uniform   y[n+1]                 8 B/node, X_i from a closed form:
+//             formula 0: fma(i, dx, x0)   (mi_grid1_create_uniform)
+//             formula 1: x0 + i*dx        (two roundings; numpy.linspace-style)
+//             formula 2: x0 + span*(i/(n-1))          (IEEE division)
+//             formula 3: as 2, the quotient by a 3-op Markstein step
+//                        q0 = i*y, q = fma(fma(-den,q0,i), y, q0), y = RN(1/den);
+//                        tried before formula 2 and accepted only if it reproduces
+//                        every node bit for bit, so it needs no rounding proof
+//           An EXPLICIT grid whose every node is reproduced bit for bit by one of
+//           these forms (checked node by node at build time; the last node may be
+//           an exception, as linspace pins it) is stored this way too: half the
+//           table bytes and one 16-B gather per query instead of 32 B.
 //   mode 1  explicit + guess   {x,y}[n+1]            16 B/node, one 32-B gather/query
 //   mode 2  explicit + buckets {x,y}[n+1] + u32[nb+1] bucket index, then a
 //           binary search confined to the bucket's node range
@@ -33,6 +44,10 @@ struct G1Dev {
     double xmin, xmax;
     double scale;        // mode 0: 1/dx; mode 1: (n-1)/(xmax-xmin); mode 2: nb/(xmax-xmin)
     double x0, dx;       // mode 0
+    double span, den;    // mode 0, formulas 2, 3
+    double rden;         // RN(1/den), formula 3
+    int formula;         // mode 0: closed form of the abscissae
+    int pin_last;        // mode 0: node n-1 is xmax exactly (not the closed form)
 };
 
 struct mi_grid1 {
@@ -62,12 +77,26 @@ __device__ __forceinline__ double blend(double xa, double ya, double xb, double 
     return (1.0 - w) * ya + w * yb;
 }
 
-__device__ __forceinline__ double unode(const G1Dev& g, int i) { return fma((double)i, g.dx, g.x0); }
+// abscissa of node i of an implicit grid; must stay in sync with host_unode() below
+template <int FORMULA>
+__device__ __forceinline__ double unode(const G1Dev& g, int i)
+{
+    double x;
+    if constexpr (FORMULA == 0) x = fma((double)i, g.dx, g.x0);
+    else if constexpr (FORMULA == 1) x = g.x0 + (double)i * g.dx;
+    else if constexpr (FORMULA == 2) x = g.x0 + g.span * ((double)i / g.den);
+    else {
+        const double q0 = (double)i * g.rden;
+        x = g.x0 + g.span * fma(fma(-g.den, q0, (double)i), g.rden, q0);
+    }
+    if (g.pin_last && i == g.n - 1) x = g.xmax;
+    return x;
+}
 
 // NQ independent queries per lane: all guesses first, then all gathers (so the
 // loads of the NQ queries are in flight together), then the rare fix-up walks
 // and the blend.
-template <int MODE, int NQ>
+template <int MODE, int NQ, int FORMULA = 0>
 __device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ], double (&out)[NQ],
                                            double extrap)
 {
@@ -81,21 +110,23 @@ __device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ]
     }
     if constexpr (MODE == 0) {
         ypair yp[NQ];
+        double xl[NQ], xr[NQ];
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
             int i = (int)((qs[k] - g.x0) * g.scale);
             i = min(max(i, 0), g.n - 1);
-            while (i > 0 && unode(g, i) > qs[k]) --i;
-            while (i < g.n - 1 && unode(g, i + 1) <= qs[k]) ++i;
+            // invariant: xl = node(i), xr = node(min(i+1, n-1)); the walks are rare (rounding of the guess)
+            double a = unode<FORMULA>(g, i), b = unode<FORMULA>(g, min(i + 1, g.n - 1));
+            while (i > 0 && a > qs[k]) { --i; b = a; a = unode<FORMULA>(g, i); }
+            while (i < g.n - 1 && b <= qs[k]) { ++i; a = b; b = unode<FORMULA>(g, min(i + 1, g.n - 1)); }
             l[k] = i;
+            xl[k] = a;
+            xr[k] = b;
         }
 #pragma unroll
         for (int k = 0; k < NQ; ++k) yp[k] = *reinterpret_cast<const ypair*>(g.y + l[k]);
 #pragma unroll
-        for (int k = 0; k < NQ; ++k) {
-            const int r = min(l[k] + 1, g.n - 1);
-            out[k] = blend(unode(g, l[k]), yp[k].a, unode(g, r), yp[k].b, qs[k]);
-        }
+        for (int k = 0; k < NQ; ++k) out[k] = blend(xl[k], yp[k].a, xr[k], yp[k].b, qs[k]);
     } else {
         d2 n0[NQ], n1[NQ];
         if constexpr (MODE == 1) {
@@ -147,7 +178,7 @@ __device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ]
 // Vector kernel: each lane streams 16 B (two queries) per step with
 // non-temporal loads/stores (the streams must not evict the table from L2),
 // UNROLL steps per iteration.  Requires xq and yq 16-B aligned.
-template <int MODE, int UNROLL>
+template <int MODE, int UNROLL, int FORMULA>
 __global__ __launch_bounds__(kBlock) void interp1_vec_kernel(G1Dev g, const double* __restrict__ xq,
                                                              double* __restrict__ yq, size_t nq,
                                                              double extrap)
@@ -166,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void interp1_vec_kernel(G1Dev g, const doub
             q[2 * u] = v.x;
             q[2 * u + 1] = v.y;
         }
-        eval_batch<MODE, 2 * UNROLL>(g, q, r, extrap);
+        eval_batch<MODE, 2 * UNROLL, FORMULA>(g, q, r, extrap);
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             d2 v;
@@ -178,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void interp1_vec_kernel(G1Dev g, const doub
     for (; i < nvec; i += stride) {
         const d2 v = __builtin_nontemporal_load(xv + i);
         double q[2] = {v.x, v.y}, r[2];
-        eval_batch<MODE, 2>(g, q, r, extrap);
+        eval_batch<MODE, 2, FORMULA>(g, q, r, extrap);
         d2 o;
         o.x = r[0];
         o.y = r[1];
@@ -186,13 +217,13 @@ __global__ __launch_bounds__(kBlock) void interp1_vec_kernel(G1Dev g, const doub
     }
     if ((nq & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         double q[1] = {xq[nq - 1]}, r[1];
-        eval_batch<MODE, 1>(g, q, r, extrap);
+        eval_batch<MODE, 1, FORMULA>(g, q, r, extrap);
         yq[nq - 1] = r[0];
     }
 }
 
 // Scalar kernel for unaligned query/result pointers.
-template <int MODE>
+template <int MODE, int FORMULA>
 __global__ __launch_bounds__(kBlock) void interp1_scalar_kernel(G1Dev g, const double* __restrict__ xq,
                                                                 double* __restrict__ yq, size_t nq,
                                                                 double extrap)
@@ -200,23 +231,23 @@ __global__ __launch_bounds__(kBlock) void interp1_scalar_kernel(G1Dev g, const d
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nq; i += stride) {
         double q[1] = {xq[i]}, r[1];
-        eval_batch<MODE, 1>(g, q, r, extrap);
+        eval_batch<MODE, 1, FORMULA>(g, q, r, extrap);
         yq[i] = r[0];
     }
 }
 
-template <int MODE>
+template <int MODE, int FORMULA = 0>
 mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, const double* xq, double* yq, size_t nq, double extrap)
 {
     const bool aligned = ((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq)) & 15u) == 0;
     if (aligned) {
         constexpr int UNROLL = 2;
         const unsigned grid = mi::stream_grid(ctx, (nq / 2 + UNROLL - 1) / UNROLL, kBlock);
-        hipLaunchKernelGGL((interp1_vec_kernel<MODE, UNROLL>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, xq,
+        hipLaunchKernelGGL((interp1_vec_kernel<MODE, UNROLL, FORMULA>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, xq,
                            yq, nq, extrap);
     } else {
         const unsigned grid = mi::stream_grid(ctx, nq, kBlock);
-        hipLaunchKernelGGL((interp1_scalar_kernel<MODE>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, xq, yq,
+        hipLaunchKernelGGL((interp1_scalar_kernel<MODE, FORMULA>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, xq, yq,
                            nq, extrap);
     }
     MI_LAUNCH_CHECK(ctx, "interp1 kernel");
@@ -234,6 +265,50 @@ mi_status upload(mi_ctx* ctx, void** dev, const void* host, size_t bytes)
     return MI_OK;
 }
 
+inline double host_unode(int formula, double x0, double dx, double span, double den, size_t i)
+{
+    if (formula == 0) return std::fma((double)i, dx, x0);
+    if (formula == 1) return x0 + (double)i * dx;
+    if (formula == 2) return x0 + span * ((double)i / den);
+    const double rden = 1.0 / den, q0 = (double)i * rden;
+    return x0 + span * std::fma(std::fma(-den, q0, (double)i), rden, q0);
+}
+
+// Does a closed form reproduce EVERY node of xs bit for bit (the last one may be pinned)?  Fills d on success.
+bool detect_closed_form(const std::vector<double>& xs, G1Dev* d)
+{
+    const size_t n = xs.size();
+    if (n < 3) return false;
+    const double x0 = xs[0], xl = xs[n - 1], den = (double)(n - 1), span = xl - x0;
+    const double dx_cands[2] = {span / den, xs[1] - xs[0]};
+    const int order[4] = {0, 1, 3, 2};   // cheapest evaluation first
+    for (int fi = 0; fi < 4; ++fi) {
+        const int formula = order[fi];
+        for (int c = 0; c < (formula >= 2 ? 1 : 2); ++c) {
+            const double dx = dx_cands[c];
+            if (!(dx > 0.0) || !std::isfinite(dx)) continue;
+            bool ok = true;
+            for (size_t i = 0; i + 1 < n && ok; ++i) ok = host_unode(formula, x0, dx, span, den, i) == xs[i];
+            if (!ok) continue;
+            const bool last_ok = host_unode(formula, x0, dx, span, den, n - 1) == xl;
+            // the closed-form abscissae must be strictly increasing up to the (possibly pinned) last node
+            if (!last_ok && !(host_unode(formula, x0, dx, span, den, n - 2) < xl)) continue;
+            d->x0 = x0;
+            d->dx = dx;
+            d->span = span;
+            d->den = den;
+            d->rden = 1.0 / den;
+            d->formula = formula;
+            d->pin_last = last_ok ? 0 : 1;
+            d->xmin = x0;
+            d->xmax = xl;
+            d->scale = 1.0 / dx;
+            return true;
+        }
+    }
+    return false;
+}
+
 // xs strictly increasing, finite, n >= 2
 mi_status build_explicit(mi_ctx* ctx, const std::vector<double>& xs, const std::vector<double>& ys, mi_grid1** out)
 {
@@ -244,6 +319,23 @@ mi_status build_explicit(mi_ctx* ctx, const std::vector<double>& xs, const std::
     g->ctx = ctx;
     g->n = n;
     g->dev_nodes = g->dev_s = nullptr;
+    {   // linspace-like explicit grid: keep only Y, recompute X in registers (bit-exact by construction)
+        G1Dev cf;
+        memset(&cf, 0, sizeof(cf));
+        if (detect_closed_form(xs, &cf)) {
+            std::vector<double> yp(ys);
+            yp.push_back(ys[n - 1]);
+            mi_status st = upload(ctx, &g->dev_nodes, yp.data(), (n + 1) * sizeof(double));
+            if (st != MI_OK) { delete g; return st; }
+            cf.y = (const double*)g->dev_nodes;
+            cf.n = (int)n;
+            g->d = cf;
+            g->mode = 0;
+            g->table_bytes = (n + 1) * sizeof(double);
+            *out = g;
+            return MI_OK;
+        }
+    }
     std::vector<d2> nodes(n + 1);
     for (size_t i = 0; i < n; ++i) {
         nodes[i].x = xs[i];
@@ -442,7 +534,11 @@ mi_status mi_interp1_f64_dev(mi_ctx* ctx, const mi_grid1* g, const double* xq, d
     MI_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq)) & 7u) == 0,
                "mi_interp1_f64_dev: pointers must be 8-byte aligned");
     switch (g->mode) {
-        case 0: return launch_mode<0>(ctx, g->d, xq, yq, nq, extrap);
+        case 0:
+            if (g->d.formula == 1) return launch_mode<0, 1>(ctx, g->d, xq, yq, nq, extrap);
+            if (g->d.formula == 2) return launch_mode<0, 2>(ctx, g->d, xq, yq, nq, extrap);
+            if (g->d.formula == 3) return launch_mode<0, 3>(ctx, g->d, xq, yq, nq, extrap);
+            return launch_mode<0, 0>(ctx, g->d, xq, yq, nq, extrap);
         case 1: return launch_mode<1>(ctx, g->d, xq, yq, nq, extrap);
         default: return launch_mode<2>(ctx, g->d, xq, yq, nq, extrap);
     }

@@ -71,8 +71,9 @@ def cpu_baseline(X, Y, nq_total):
     """The CPU oracle (kind 'port': the repo's restatement of arma::interp1 semantics, bracket formulation,
     OpenMP over queries) on a bounded sample of the same workload, on this box's host cores."""
     import oracle
-    threads = min(oracle.max_threads(), os.cpu_count() or 1)
-    n = 20_000_000
+    # a 1-GPU box's CPU share is 16 threads (more are visible but belong to other tenants)
+    threads = min(oracle.max_threads(), os.cpu_count() or 1, 16)
+    n = 50_000_000
     xi = oracle.splitmix_uniform(SEED_Q, n)
     oracle.interp1_bracket(X, Y, xi[:1_000_000], nthreads=threads)      # warm caches / thread pool
     best = None
@@ -81,9 +82,32 @@ def cpu_baseline(X, Y, nq_total):
         oracle.interp1_bracket(X, Y, xi, nthreads=threads)
         dt = time.perf_counter() - t
         best = dt if best is None else min(best, dt)
+    # the literal single-threaded arma::interp1 algorithm (sort XI, resumed scan, un-permute) on a smaller sample
+    m = 4_000_000
+    t = time.perf_counter()
+    oracle.interp1_arma(X, Y, xi[:m])
+    t_arma = time.perf_counter() - t
     return {"value": n / best, "unit": "points/s", "cores": threads, "kind": "port",
             "sample": "first %d of the %d SplitMix64 queries (seed 0x5EED0003), same 1e6-node table, "
-                      "oracle.interp1_bracket, best of 2, %.2f s per pass" % (n, nq_total, best)}
+                      "oracle.interp1_bracket (OpenMP), best of 2, %.2f s per pass" % (n, nq_total, best),
+            "arma_interp1_semantics_1thread_points_per_s": m / t_arma,
+            "arma_interp1_semantics_sample": "oracle.interp1_arma (sort + resumed scan + un-permute, the literal "
+                                             "Armadillo algorithm) on the first %d queries, %.2f s" % (m, t_arma)}
+
+
+def measured_traffic(mode, queries, nq):
+    """HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately by
+    scripts/profile_bench.sh and corrected as MI355X_MICROARCH.md section HBM prescribes); None when the
+    committed profile does not cover this kernel/configuration."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        t = json.load(open(path))
+        e = t.get("interp1_mode%d_%s" % (mode, queries))
+        if e and int(e.get("nq", 0)) == int(nq):
+            return e["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def main():
@@ -166,7 +190,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(ginfo["mode"], args.queries, nq),
             "kernel": "interp1_vec_kernel<%d,2>" % ginfo["mode"],
             "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
             "note": "achieved = (16 B/query + table bytes) / HIP-event time per launch; traffic: see profiles/",

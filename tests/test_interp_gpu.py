@@ -108,7 +108,7 @@ def test_ragged_sizes_all_modes(mi_ctx, nq):
     ng = 4097
     u = oracle.splitmix_uniform(1234, ng)
     grids = {
-        "uniformX": (np.arange(ng) / (ng - 1), 1),
+        "uniformX": (np.arange(ng) / (ng - 1), 0),            # closed form detected -> implicit table
         "jitterX": ((np.arange(ng) + 0.5 * u) / ng, 1),
         "clustered": (np.unique(np.sort(u ** 5)), 2),
     }
@@ -132,6 +132,35 @@ def test_ragged_sizes_all_modes(mi_ctx, nq):
     gu = mi.Grid1.uniform(mi_ctx, x0, dx, Y)
     qu = q * 1.2 + x0
     assert _eq(gu.interp(_t(qu)).cpu().numpy(), oracle.interp1_uniform(x0, dx, Y, qu))
+
+
+def test_closed_form_detection_is_bit_exact(mi_ctx):
+    """Explicit grids that a closed form reproduces bit for bit are stored as Y only (mode 0); the result must
+    still equal the oracle evaluated on the EXPLICIT abscissae, everywhere including one ulp around every node."""
+    import armadillocudalinearinterpolation_amd as mi
+    n = 20001
+    grids = {
+        "i/(n-1)": np.arange(n) / (n - 1),
+        "linspace": np.linspace(-2.5, 7.25, n),                 # last node pinned to the stop value
+        "x0+i*dx": 0.1 + 0.3 * np.arange(n),
+        "fma-like": -1.0 + 2.0 ** -7 * np.arange(n),
+        "span*(i/den)": 3.0 + 5.0 * (np.arange(n) / (n - 1)),
+    }
+    for name, X in grids.items():
+        Y = np.sin(X) + 0.01 * X * X
+        g = mi.Grid1.from_nodes(mi_ctx, X, Y)
+        assert g.info()["mode"] == 0, name
+        assert g.info()["table_bytes"] == 8 * (n + 1)
+        q = np.concatenate([X, np.nextafter(X, np.inf), np.nextafter(X, -np.inf), 0.5 * (X[1:] + X[:-1]),
+                            oracle.splitmix_uniform(5, 50000) * (X[-1] - X[0]) * 1.01 + X[0]])
+        assert _eq(g.interp(_t(q)).cpu().numpy(), oracle.interp1_bracket(X, Y, q)), name
+    # one perturbed node breaks the closed form -> explicit table (mode 1), still exact
+    X = np.arange(n) / (n - 1)
+    X[777] = np.nextafter(X[777], 1.0)
+    g = mi.Grid1.from_nodes(mi_ctx, X, np.cos(X))
+    assert g.info()["mode"] == 1
+    q = oracle.splitmix_uniform(6, 50000)
+    assert _eq(g.interp(_t(q)).cpu().numpy(), oracle.interp1_bracket(X, np.cos(X), q))
 
 
 def test_queries_on_nodes_and_cell_midpoints(mi_ctx):
