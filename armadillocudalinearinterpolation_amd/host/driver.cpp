@@ -1,0 +1,74 @@
+// The reference's fixed problem (Driver.cu:11-126) on the MI355X path: beta = 13.0589, Z0 = (0.3310, 0.6914,
+// 1.3557), Newton tolerance 1e-4, max 10 iterations, forward-difference epsilon 1e-2, damping 1, 512 grid points.
+//   driver [--real R] [--threads N] [--fast] [--debug DIR] [--json FILE] [--quiet]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+#include "event_driven_map.hpp"
+#include "newton_solver.hpp"
+
+int main(int argc, char* argv[])
+{
+    unsigned int noReal = 1000;        // Driver.cu:19
+    int noThreads = 512;               // Driver.cu:69
+    bool fast = false, quiet = false;
+    const char *debug_dir = nullptr, *json = nullptr;
+    for (int i = 1; i < argc; ++i) {
+        if (!std::strcmp(argv[i], "--real") && i + 1 < argc) noReal = std::strtoul(argv[++i], nullptr, 10);
+        else if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) noThreads = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--fast")) fast = true;
+        else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
+        else if (!std::strcmp(argv[i], "--debug") && i + 1 < argc) debug_dir = argv[++i];
+        else if (!std::strcmp(argv[i], "--json") && i + 1 < argc) json = argv[++i];
+        else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+    }
+
+    arma::vec parameters(1);
+    parameters(0) = 13.0589f;                                   // Driver.cu:16 (a float literal)
+    EventDrivenMap event(&parameters, noReal);
+    event.SetQuiet(quiet);
+    if (fast) event.SetMathMode(MI_EDM_MATH_FAST);
+
+    arma::vec guess(3);                                          // Driver.cu:23-24 (float literals)
+    guess(0) = 0.3310f; guess(1) = 0.6914f; guess(2) = 1.3557f;
+
+    NewtonSolver::ParameterList pars;                            // Driver.cu:27-37
+    pars.tolerance = 1e-4;
+    pars.maxIterations = 10;
+    pars.printOutput = !quiet;
+    pars.damping = 1.0;
+    NewtonSolver newton(&event, &guess, &pars);
+    pars.finiteDifferenceEpsilon = 1e-2;                         // set after construction; read live at Solve()
+
+    arma::vec f0(3);
+    event.ComputeF(guess, f0);                                   // Driver.cu:59: one residual at N = 1024
+    if (!quiet) std::cout << "F(Z0) at 1024 grid points =\n" << f0 << std::endl;
+
+    event.SetNoThreads(noThreads);                               // Driver.cu:69
+    if (debug_dir) { event.SetDebugDirectory(debug_dir); event.SetDebugFlag(true); }   // Driver.cu:70
+    arma::vec solution(3), history;
+    AbstractNonlinearSolver::ExitFlagType flag;
+    const auto t0 = std::chrono::steady_clock::now();
+    newton.Solve(solution, history, flag);                       // Driver.cu:71
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!quiet) std::cout << "Homogeneous Solution = \n" << solution << std::endl;
+
+    const bool ok = flag == AbstractNonlinearSolver::ExitFlagType::converged;
+    if (json) {
+        FILE* fp = std::fopen(json, "w");
+        if (fp) {
+            std::fprintf(fp, "{\"converged\": %s, \"iterations\": %d, \"residual_evaluations\": %d, \"n_real\": %u, "
+                             "\"n_grid\": %d, \"math\": \"%s\", \"solve_seconds\": %.6f,\n \"solution\": [%.17g, %.17g, %.17g],\n"
+                             " \"f0_1024\": [%.17g, %.17g, %.17g],\n \"history\": [",
+                         ok ? "true" : "false", newton.LastIterationCount(), newton.LastResidualEvaluations(), noReal,
+                         noThreads, fast ? "fast" : "exact", secs, solution(0), solution(1), solution(2), f0(0), f0(1), f0(2));
+            for (int i = 0; i <= newton.LastIterationCount(); ++i) std::fprintf(fp, "%s%.17g", i ? ", " : "", history(i));
+            std::fprintf(fp, "]}\n");
+            std::fclose(fp);
+        }
+    }
+    return ok ? 0 : 1;
+}

@@ -1,0 +1,55 @@
+// EventDrivenMap: the reference's concrete problem (EventDrivenMap.hpp:11-121)
+// as a thin C++ host class over the C ABI.  Same public interface, so
+// `new EventDrivenMap(p_parameters, noReal)` and `NewtonSolver(p_event, ...)`
+// read exactly like Driver.cu:20,34.  All device work (lift, evolve, restrict,
+// average) happens in libmi355interp.so; this class only owns the handle, the
+// parameter block and the optional debug dumps.
+#pragma once
+#include <string>
+
+#include "mi355_interp.h"
+#include "nonlinear_problem.hpp"
+
+class EventDrivenMap : public AbstractNonlinearProblem {
+  public:
+    EventDrivenMap(const arma::vec* pParameters, unsigned int noReal, int device = 0);
+    ~EventDrivenMap() override;
+    EventDrivenMap(const EventDrivenMap&) = delete;              // the reference's copy would double-free
+    EventDrivenMap& operator=(const EventDrivenMap&) = delete;
+
+    // residual f(Z), Z = (c, Z1, .., Z_{S-1})   (EventDrivenMap.cu:154-240)
+    void ComputeF(const arma::vec& u, arma::vec& f) override;
+
+    // setters of EventDrivenMap.hpp:27-51 (each echoes to stdout like the reference)
+    void SetTimeHorizon(const float T);
+    void SetNoRealisations(const int noReal);
+    void SetNoThreads(const int noThreads);          // grid points; the reference asserts < 1024, here <= 1024
+    void SetParameterStdDev(const float sigma);
+    void SetParameters(const unsigned int parId, const float parVal);
+    void ResetSeed();                                // no-op: the counter-based draw restarts every ComputeF
+    void SetNewSeed();                               // clock-derived, like EventDrivenMap.cu:337-341
+    void SetSeed(unsigned long long seed);           // reproducible alternative
+    void PostProcess() override;                     // = SetNewSeed (EventDrivenMap.cu:343-346)
+    void SetDebugFlag(const bool val);               // Save* dumps, EventDrivenMap.cu:406-503
+
+    // extensions (not in the reference)
+    void SetMathMode(int mode);                      // MI_EDM_MATH_EXACT / MI_EDM_MATH_FAST
+    void SetRealisationOffset(unsigned int offset);  // this rank's first global realisation (multi-GPU shards)
+    void SetDebugDirectory(const std::string& dir) { debug_dir_ = dir; }
+    void SetQuiet(bool q) { quiet_ = q; }
+    // un-normalised accepted sums (S values) + accepted count of the last ComputeF, for an all-reduce
+    const arma::vec& LastPartialSums() const { return partial_; }
+    void ResidualFromSums(const arma::vec& u, const arma::vec& sums_and_count, arma::vec& f) const;
+    const mi_edm_params& Parameters() const { return p_; }
+    void LastTimingsMs(float ms[4]) const;
+
+  private:
+    void Push();
+    void Dump();
+    mi_ctx* ctx_;
+    mi_edm* edm_;
+    mi_edm_params p_;
+    arma::vec partial_;
+    bool debug_ = false, quiet_ = false;
+    std::string debug_dir_ = ".";
+};

@@ -1,0 +1,23 @@
+// Operator boundary of the solver framework: the two abstract interfaces the
+// reference declares in AbstractNonlinearProblem.hpp:6-14 and
+// AbstractNonlinearProblemJacobian.hpp:6-13, with the same class names and
+// virtual signatures so that a NewtonSolver written against the reference
+// headers drives EventDrivenMap (event_driven_map.hpp) unchanged.
+#pragma once
+#include "mi355_arma_compat.hpp"
+
+// residual F(u) of a nonlinear problem F(u) = 0
+class AbstractNonlinearProblem {
+  public:
+    virtual ~AbstractNonlinearProblem() {}
+    virtual void ComputeF(const arma::vec& u, arma::vec& f) = 0;
+    // hook run by the solver once a Solve() has finished (default: nothing)
+    virtual void PostProcess() {}
+};
+
+// optional analytic Jacobian dF/du
+class AbstractNonlinearProblemJacobian {
+  public:
+    virtual ~AbstractNonlinearProblemJacobian() {}
+    virtual void ComputeDFDU(const arma::vec& u, arma::mat& dfdu) = 0;
+};

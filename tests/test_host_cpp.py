@@ -1,0 +1,123 @@
+"""The C++ host layer (armadillocudalinearinterpolation_amd/host + include/mi355_arma*.hpp).
+
+CPU part: it compiles with plain g++ (Armadillo when installed, otherwise the stand-in) and its Newton loop /
+linear algebra self-test passes.  GPU part: the Armadillo-facing wrappers and the Driver.cu problem run on
+the MI355X and agree with the oracle (wrappers: bit-exact; Newton root: within the solver tolerance)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "armadillocudalinearinterpolation_amd", "host")
+
+
+def _build():
+    from armadillocudalinearinterpolation_amd import _build as b
+    b.build_lib()
+    subprocess.check_call(["make", "-s", "-C", HOST, "all"])
+
+
+def test_host_layer_builds_and_selftest_passes():
+    _build()
+    out = subprocess.run([os.path.join(HOST, "host_selftest")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all passed" in out.stdout
+
+
+def _lcg_queries(n, seed, scale, shift):
+    s, out = seed, np.empty(n)
+    for i in range(n):
+        s = (s * 6364136223846793005 + 1442695040888963407) & (2**64 - 1)
+        out[i] = (s >> 11) * 2.0 ** -53 * scale + shift
+    return out, s
+
+
+@pytest.mark.gpu
+def test_arma_wrappers_match_oracle(tmp_path):
+    _build()
+    out = subprocess.run([os.path.join(HOST, "arma_wrappers_test"), str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    ng, nq = 10000, 100000
+    X = np.arange(ng) / (ng - 1)
+    Y = np.sin(6.283185307179586 * X) + 0.5 * X
+    XI, s = _lcg_queries(nq, 42, 1.1, -0.05)
+    rd = lambda f: np.fromfile(os.path.join(tmp_path, f), dtype=np.float64)  # noqa: E731
+    ref = oracle.interp1_arma(X, Y, XI)
+    assert np.array_equal(rd("w_interp1.bin"), ref, equal_nan=True)
+    assert np.array_equal(rd("w_table_nan.bin"), ref, equal_nan=True)
+    assert np.array_equal(rd("w_table_extrap.bin"), oracle.interp1_arma(X, Y, XI, extrap=-1.0))
+    nx, ny, n2 = 40, 25, 20000
+    xg = np.array([0.1 * j * (1.0 + 0.01 * j) for j in range(nx)])
+    yg = np.array([-1.0 + 0.2 * i for i in range(ny)])
+    Z = np.sin(xg)[None, :] * np.cos(yg)[:, None] + 0.1 * xg[None, :] * yg[:, None]
+    xq, yq = np.empty(n2), np.empty(n2)
+    for k in range(n2):
+        s = (s * 6364136223846793005 + 1442695040888963407) & (2**64 - 1)
+        xq[k] = (s >> 11) * 2.0 ** -53 * (xg[-1] + 0.2) - 0.1
+        s = (s * 6364136223846793005 + 1442695040888963407) & (2**64 - 1)
+        yq[k] = (s >> 11) * 2.0 ** -53 * 5.2 - 1.1
+    # libm sin/cos of the C++ program and numpy agree on this platform (same glibc); compare to 1e-15 to be safe
+    got = rd("w_interp2.bin")
+    ref2 = oracle.interp2_bilinear(xg, yg, Z, xq, yq)
+    assert np.array_equal(np.isnan(got), np.isnan(ref2))
+    assert np.nanmax(np.abs(got - ref2)) < 1e-14
+
+
+def _newton_on_oracle(p, Z0, tol, max_it, eps, damping=1.0):
+    """tests-only restatement of NewtonSolver.cpp:40-197 driving the ORACLE residual"""
+    u = np.array(Z0, dtype=np.float64)
+    seed = None
+    f, d = oracle.edm_compute_f(p, u, seed_ind=seed, nthreads=8, debug=True)
+    seed = d["seed_ind"]
+    hist, it = [np.linalg.norm(f)], 0
+    while it < max_it and not hist[-1] <= tol:
+        J = np.empty((3, 3))
+        for i in range(3):
+            du = u.copy()
+            du[i] += eps
+            df, d = oracle.edm_compute_f(p, du, seed_ind=seed, nthreads=8)
+            seed = d["seed_ind"]
+            J[:, i] = (df - f) * eps ** -1
+        u = u + damping * np.linalg.solve(J, -f)
+        it += 1
+        f, d = oracle.edm_compute_f(p, u, seed_ind=seed, nthreads=8)
+        seed = d["seed_ind"]
+        hist.append(np.linalg.norm(f))
+    return u, hist, it
+
+
+@pytest.mark.gpu
+def test_driver_newton_solve_matches_oracle_newton(tmp_path):
+    """BASELINE config 5 at 1 GPU: the Driver.cu problem (tol 1e-4, maxIt 10, FD eps 1e-2, 512 grid points)."""
+    _build()
+    js = os.path.join(tmp_path, "driver.json")
+    dbg = os.path.join(tmp_path, "dumps")
+    os.makedirs(dbg)
+    out = subprocess.run([os.path.join(HOST, "driver"), "--real", "1000", "--json", js, "--debug", dbg],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "The method converged after" in out.stdout and "Newton Method" in out.stdout
+    r = json.load(open(js))
+    assert r["converged"] and r["iterations"] <= 10
+    assert r["residual_evaluations"] == 1 + 4 * r["iterations"]
+    # sigma = 0: the residual does not depend on the number of realisations, so 2 oracle realisations suffice
+    Z0 = [float(np.float32(0.3310)), float(np.float32(0.6914)), float(np.float32(1.3557))]
+    p = oracle.edm_default_params(n_grid=512, n_real=2)
+    u, hist, it = _newton_on_oracle(p, Z0, 1e-4, 10, 1e-2)
+    assert it == r["iterations"]
+    assert np.allclose(r["solution"], u, rtol=0, atol=1e-4)                 # same root within the Newton tolerance
+    assert np.allclose(r["history"], hist, rtol=0, atol=5e-6)
+    assert r["history"][-1] <= 1e-4
+    f1024, _ = oracle.edm_compute_f(oracle.edm_default_params(n_real=2), Z0)
+    assert np.allclose(r["f0_1024"], f1024, rtol=0, atol=2e-7)
+    # debug taps (the reference's Save* dumps): one %f per line, sizes S*R / R / N / S
+    n = lambda f: sum(1 for _ in open(os.path.join(dbg, f)))  # noqa: E731
+    assert n("testAverages.dat") == 3000 and n("testAcceptFlag.dat") == 1000 and n("testLift.dat") == 512
+    assert n("testAveraged.dat") == 3 and n("testLastSpikeTime.dat") == 3000 and n("test.dat") == 512
+    acc = np.loadtxt(os.path.join(dbg, "testAcceptFlag.dat"))
+    assert np.all(acc == 1.0)
