@@ -66,6 +66,21 @@ def main():
                 "note": "corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts 128-B read requests "
                         "as 64 B (exact for the 16 B/lane query stream; the table-gather share is uncalibrated and "
                         "may be over-corrected)"}
+    # profiles/traffic_latest.json: what bench.py reports as roofline.traffic (keyed by table mode + query set)
+    import re
+    queries = sys.argv[3] if len(sys.argv) > 3 else "random"
+    nq = int(sys.argv[4]) if len(sys.argv) > 4 else 100000000
+    latest = {}
+    for k, t in summary.get("traffic", {}).items():
+        m = re.search(r"interp1_vec_kernel<(\d+)", k)
+        if m:
+            latest["interp1_mode%s_%s" % (m.group(1), queries)] = {
+                "nq": nq, "hbm_bytes_per_launch": t["hbm_bytes_per_launch_corrected"],
+                "hbm_bytes_per_launch_raw": t["hbm_bytes_per_launch_raw"], "kernel": k, "profile": "summary_%s.json" % tag,
+                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                          "(gfx950 FETCH_SIZE halves wide reads, MI355X_MICROARCH.md section HBM); Infinity-Cache hits are counted"}
+    if latest:
+        json.dump(latest, open(os.path.join(out_dir, "traffic_latest.json"), "w"), indent=1)
     dst = os.path.join(out_dir, "summary_%s.json" % tag)
     json.dump(summary, open(dst, "w"), indent=1)
     for k, v in summary["kernels"].items():
