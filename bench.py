@@ -43,6 +43,10 @@ def parse():
                     "implicit-uniform table, config 3, restrict+mean, all-gather)")
     ap.add_argument("--table", choices=["general", "uniform"], default="general")
     ap.add_argument("--queries", choices=["random", "sorted", "uniform"], default="random")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI, the real thing) or gloo "
+                    "(rehearsal of the N>1 code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--rehearse-one-device", action="store_true",
+                    help="map every rank to cuda:0 (only with --dist-backend gloo; timings are then meaningless)")
     return ap.parse_args()
 
 
@@ -129,11 +133,17 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    if args.rehearse_one_device:
+        assert args.dist_backend == "gloo", "--rehearse-one-device needs --dist-backend gloo"
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
         def barrier():
             dist.barrier()
@@ -232,7 +242,7 @@ def main():
         s = quick(lambda: mi.restrict_mean(ctx, t0, i0, t1, i1, acc, 5.0, 3.0, 1024, S))
         extra["restrict_mean_3x1e6"] = {"ms": s * 1e3, "elements_per_s": S * R / s,
                                          "GBps": (12.0 * S * R + 4.0 * R) / s / 1e9}
-    if world > 1 and not args.no_extra:
+    if world > 1 and not args.no_extra and args.dist_backend == "nccl":
         full = torch.empty(world * nq, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(full, yq)
         torch.cuda.synchronize()
