@@ -148,17 +148,34 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
         }
         unsigned crossed = 0;
         float now = 0.0f;
+        // Candidate bookkeeping.  Every event needs min over neurons of eventTime().  Neurons that will not
+        // fire contribute exactly kNever; the few that will (the bump fronts) need a divergent Newton solve.
+        // Instead of running that loop once per 64-neuron slice, each lane records its firing neurons in a
+        // bitmask (bit k <-> neuron k*64+lane) during the state pass and the solves then run in compacted
+        // rounds: one round handles one pending neuron of EVERY lane.  The (time, index) minimum is taken
+        // lexicographically, so the result does not depend on evaluation order ([D1]).
+        float base_t = INFINITY;      // min over this lane's non-firing neurons: kNever at the lowest such index
+        unsigned base_i = 0;
+        unsigned pend = 0;
+        for (unsigned k = 0; k < npl; ++k) {
+            const unsigned i = k * 64u + lane;
+            if (i < M.N) {
+                const float bk = HETERO ? B[i] : M.beta_mean;
+                if (edm::will_fire<MATH>(M, V[i], S[i], bk)) pend |= (1u << k);
+                else if (base_t == INFINITY) { base_t = edm::kNever; base_i = i; }
+            }
+        }
         while (crossed < full && now < two_T) {
-            // next firing time of every neuron; lane-local then wave arg-min
-            // ([D1]: smallest time, ties -> lowest index, NaN never wins)
-            float best = INFINITY;
-            unsigned idx = 0;
-            for (unsigned k = 0; k < npl; ++k) {
-                const unsigned i = k * 64u + lane;
-                if (i < M.N) {
+            float best = base_t;
+            unsigned idx = base_i;
+            while (__any(pend != 0u)) {
+                if (pend != 0u) {
+                    const unsigned k = (unsigned)__builtin_ctz(pend);
+                    pend &= pend - 1u;
+                    const unsigned i = k * 64u + lane;
                     const float bk = HETERO ? B[i] : M.beta_mean;
-                    const float tau = edm::event_time<MATH>(M, V[i], S[i], bk);
-                    if (tau < best) { best = tau; idx = i; }
+                    const float tau = edm::newton_time<MATH>(M, V[i], S[i], bk);
+                    if (tau < best || (tau == best && i < idx)) { best = tau; idx = i; }
                 }
             }
 #pragma unroll
@@ -168,13 +185,15 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 if (ot < best || (ot == best && oi < idx)) { best = ot; idx = oi; }
             }
             const float dt = best;
-            // analytic state advance (EventDrivenMap.cu:612-617)
+            // analytic state advance (EventDrivenMap.cu:612-617), fused with the firing test for the NEXT event
             const float e1 = edm::expf_<MATH>(-dt);
             float e2u = 0.0f, e3u = 0.0f;
             if constexpr (!HETERO) {
                 e2u = edm::expf_<MATH>((1.0f - M.beta_mean) * dt);
                 e3u = edm::expf_<MATH>(-M.beta_mean * dt);
             }
+            base_t = INFINITY;
+            base_i = 0;
             for (unsigned k = 0; k < npl; ++k) {
                 const unsigned i = k * 64u + lane;
                 const float bk = HETERO ? B[i] : M.beta_mean;
@@ -182,13 +201,17 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 const float e3 = HETERO ? edm::expf_<MATH>(-bk * dt) : e3u;
                 const float so = S[i];
                 float vv = V[i] * e1;
-                vv = vv + (M.I * (1.0f - e1) + ((so * e1) / (1.0f - bk)) * (e2 - 1.0f));
+                vv = vv + (M.I * (1.0f - e1) + edm::div_<MATH>(so * e1, 1.0f - bk) * (e2 - 1.0f));
                 vv = vv * ((i != idx) ? 1.0f : 0.0f);
                 float sn = so * e3;
                 const unsigned dist = (i >= idx) ? (i - idx) : (idx - i);
                 sn = sn + bk * w_lds[dist & (kMaxGrid - 1)];
                 V[i] = vv;
                 S[i] = sn;
+                if (i < M.N) {
+                    if (edm::will_fire<MATH>(M, vv, sn, bk)) pend |= (1u << k);
+                    else if (base_t == INFINITY) { base_t = edm::kNever; base_i = i; }
+                }
             }
             now = now + dt;
             // which bump does the event belong to ([D3]: the reference's increment rule, :625-629)
@@ -281,6 +304,7 @@ mi_status validate(const mi_ctx* ctx, const mi_edm_params* p)
     if (p->n_real < 1) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: n_real must be positive");
     if (!(p->time_horizon > 0.0f)) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: time_horizon must be > 0");
     if (!(p->beta_stddev >= 0.0f)) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: beta_stddev must be >= 0");
+    if (!(p->newton_tol >= 0.0)) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: newton_tol must be >= 0");
     if (p->math_mode != MI_EDM_MATH_EXACT && p->math_mode != MI_EDM_MATH_FAST)
         return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: unknown math_mode %d", p->math_mode);
     if ((uint64_t)p->n_spikes * p->n_real > 0xfffffff0ull)

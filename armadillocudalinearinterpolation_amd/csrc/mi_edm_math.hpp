@@ -144,38 +144,66 @@ struct FdF {
     float f, df;
 };
 
+// a / b: IEEE division in EXACT mode; v_rcp_f32 * a (about 1 ulp) in FAST mode on the device
+template <int MATH>
+MI_HD float div_(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (MATH == 1) return a * __builtin_amdgcn_rcpf(b);
+#endif
+    return a / b;
+}
+
 // fun/dfun, EventDrivenMap.cu:544-552, sharing e1 = exp(-t), e2 = exp((1-beta) t)
+template <int MATH>
 MI_HD FdF fun_dfun_e(const Model& M, float e1, float e2, float v, float s, float beta)
 {
     const float se = s * e1;
     FdF r;
-    r.f = ((v * e1 + M.I * (1.0f - e1)) + (se / (1.0f - beta)) * (e2 - 1.0f)) - M.vth;
-    r.df = ((M.I * e1 - v * e1) + se * e2) + (se * (e2 - 1.0f)) / (beta - 1.0f);
+    r.f = ((v * e1 + M.I * (1.0f - e1)) + div_<MATH>(se, 1.0f - beta) * (e2 - 1.0f)) - M.vth;
+    r.df = ((M.I * e1 - v * e1) + se * e2) + div_<MATH>(se * (e2 - 1.0f), beta - 1.0f);
     return r;
 }
 
-// eventTime, EventDrivenMap.cu:554-573.  At t = 0 both exponentials are exactly 1
-// (expf_(+-0) == 1), so the first evaluation needs no exp.
+// eventTime, EventDrivenMap.cu:554-573, split in two so that callers can batch the Newton solves:
+//   will_fire()    the closed-form test of :559 ("decision")
+//   newton_time()  the Newton iteration of :561-571 for a neuron that will fire
+// A neuron with decision false has f = fun(0)*0, i.e. +-0 or NaN: the reference's loop is not entered and
+// eventTime returns exactly |0| + 100 (requires tol >= 0, validated) -> kNever.
+// At t = 0 both exponentials are exactly 1 (expf_(+-0) == 1), so the first evaluation needs no exp.
+constexpr float kNever = 100.0f;
+
 template <int MATH>
-MI_HD float event_time(const Model& M, float v0, float s0, float beta)
+MI_HD bool will_fire(const Model& M, float v0, float s0, float beta)
 {
     const float gap = M.vth - M.I;
-    const float ratio = s0 / gap;
-    const float pw = powf_<MATH>(ratio, 1.0f / beta);
-    const float thr = (M.vth * pw + M.I * (1.0f - pw)) - (gap / (beta - 1.0f)) * (ratio - pw);
-    const bool decision = v0 > thr;
+    const float ratio = div_<MATH>(s0, gap);
+    const float pw = powf_<MATH>(ratio, div_<MATH>(1.0f, beta));
+    const float thr = (M.vth * pw + M.I * (1.0f - pw)) - div_<MATH>(gap, beta - 1.0f) * (ratio - pw);
+    return v0 > thr;
+}
+
+template <int MATH>
+MI_HD float newton_time(const Model& M, float v0, float s0, float beta)
+{
     float t = 0.0f;
-    FdF r = fun_dfun_e(M, 1.0f, 1.0f, v0, s0, beta);
-    float f = r.f * (decision ? 1.0f : 0.0f), df = r.df;
+    FdF r = fun_dfun_e<MATH>(M, 1.0f, 1.0f, v0, s0, beta);
+    float f = r.f, df = r.df;
     uint32_t counter = 0;
     while ((fabsf(f) > M.tol_f) && (counter < M.max_iter)) {
-        t = t - f / df;
-        r = fun_dfun_e(M, expf_<MATH>(-t), expf_<MATH>((1.0f - beta) * t), v0, s0, beta);
+        t = t - div_<MATH>(f, df);
+        r = fun_dfun_e<MATH>(M, expf_<MATH>(-t), expf_<MATH>((1.0f - beta) * t), v0, s0, beta);
         f = r.f;
         df = r.df;
         ++counter;
     }
-    return fabsf(t) + 100.0f * (1.0f - (decision ? 1.0f : 0.0f));
+    return fabsf(t);
+}
+
+template <int MATH>
+MI_HD float event_time(const Model& M, float v0, float s0, float beta)
+{
+    return will_fire<MATH>(M, v0, s0, beta) ? newton_time<MATH>(M, v0, s0, beta) : kNever;
 }
 
 }  // namespace edm
