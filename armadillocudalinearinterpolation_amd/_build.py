@@ -40,7 +40,8 @@ def build_lib(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libmi355interp.so cannot be built (there is no CPU fallback)")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", os.path.join(REPO_ROOT, "include"), "-I", CSRC,
+    extra = os.environ.get("MI_EXTRA_HIPCC_FLAGS", "").split()
+    cmd = [hipcc] + HIPCC_FLAGS + extra + ["-I", os.path.join(REPO_ROOT, "include"), "-I", CSRC,
                                    "-o", LIB_PATH + ".tmp"] + sources()
     if verbose:
         print(" ".join(cmd))

@@ -30,6 +30,9 @@ namespace {
 constexpr int kMaxSpikes = 8;
 constexpr int kMaxGrid = 1024;
 constexpr int kEvolveBlock = 256;   // 4 waves = 4 realisations per workgroup
+#ifndef MI_EVOLVE_UNROLL
+#define MI_EVOLVE_UNROLL 1           // state-pass unroll (measured: see DESIGN.md)
+#endif
 
 struct SpikeSeeds {
     float U[kMaxSpikes + 1];        // (c, 0, Z1, ..), fp32 (EventDrivenMap.cu:172)
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             }
             base_t = INFINITY;
             base_i = 0;
+#pragma unroll MI_EVOLVE_UNROLL
             for (unsigned k = 0; k < npl; ++k) {
                 const unsigned i = k * 64u + lane;
                 const float bk = HETERO ? B[i] : M.beta_mean;

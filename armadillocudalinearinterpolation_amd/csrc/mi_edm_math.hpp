@@ -20,11 +20,11 @@ MI_HD float expf_(float x)
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (MATH == 1) return __expf(x);
 #endif
-    if (x != x) return x;
-    if (x > 88.72283935546875f) return INFINITY;
-    if (x < -103.97208404541015625f) return 0.0f;
-    const float n = rintf(x * 0x1.715476p+0f);
-    float r = fmaf(n, -0x1.62e4p-1f, x);
+    // Branch-free: the polynomial runs on a clamped argument and the special cases are selected at the
+    // end (same values as the early-return form in oracle/edm_oracle.c for every input).
+    const float xc = fminf(fmaxf(x, -104.0f), 89.0f);
+    const float n = rintf(xc * 0x1.715476p+0f);
+    float r = fmaf(n, -0x1.62e4p-1f, xc);
     r = fmaf(n, -0x1.7f7d1cp-20f, r);
     const float z = r * r;
     float p = 0x1.a0d2bcp-13f;
@@ -35,7 +35,11 @@ MI_HD float expf_(float x)
     p = fmaf(p, r, 0x1.000002p-1f);
     p = fmaf(p, z, r);
     p = p + 1.0f;
-    return ldexpf(p, (int)n);
+    float y = ldexpf(p, (int)n);
+    y = (x > 88.72283935546875f) ? INFINITY : y;
+    y = (x < -103.97208404541015625f) ? 0.0f : y;
+    y = (x != x) ? x : y;
+    return y;
 }
 
 template <int MATH>
@@ -44,13 +48,13 @@ MI_HD float logf_(float x)
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (MATH == 1) return __logf(x);
 #endif
-    if (x != x) return x;
-    if (x < 0.0f) return NAN;
-    if (x == 0.0f) return -INFINITY;
-    if (x == INFINITY) return x;
+    const bool regular = (x > 0.0f) && (x < INFINITY);
+    const float xs = regular ? x : 1.0f;
     int e;
-    float m = frexpf(x, &e);
-    if (m < 0x1.6a09e6p-1f) { m = m + m; e -= 1; }
+    float m = frexpf(xs, &e);
+    const bool low = m < 0x1.6a09e6p-1f;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
     const float f = m - 1.0f;
     const float z = f * f;
     float p = 0x1.203736p-4f;
@@ -68,6 +72,10 @@ MI_HD float logf_(float x)
     y = fmaf(-0.5f, z, y);
     float r = f + y;
     r = fmaf(fe, 0x1.63p-1f, r);
+    r = (x == INFINITY) ? x : r;
+    r = (x == 0.0f) ? -INFINITY : r;
+    r = (x < 0.0f) ? NAN : r;
+    r = (x != x) ? x : r;
     return r;
 }
 
@@ -177,7 +185,12 @@ template <int MATH>
 MI_HD bool will_fire(const Model& M, float v0, float s0, float beta)
 {
     const float gap = M.vth - M.I;
+    // Exact shortcuts: a negative (or NaN) ratio makes log(ratio) NaN, hence pw, thr NaN and `v0 > thr` false.
+    // With 0 < gap <= 1 the quotient s0/gap cannot underflow to -0, so s0 < 0 already decides it (no division);
+    // the inhibitory surround puts most of the ring in this case, 64 contiguous neurons per wave step.
+    if (gap > 0.0f && gap <= 1.0f && s0 < 0.0f) return false;
     const float ratio = div_<MATH>(s0, gap);
+    if (!(ratio >= 0.0f)) return false;
     const float pw = powf_<MATH>(ratio, div_<MATH>(1.0f, beta));
     const float thr = (M.vth * pw + M.I * (1.0f - pw)) - div_<MATH>(gap, beta - 1.0f) * (ratio - pw);
     return v0 > thr;

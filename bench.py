@@ -242,6 +242,19 @@ def main():
         s = quick(lambda: mi.restrict_mean(ctx, t0, i0, t1, i1, acc, 5.0, 3.0, 1024, S))
         extra["restrict_mean_3x1e6"] = {"ms": s * 1e3, "elements_per_s": S * R / s,
                                          "GBps": (12.0 * S * R + 4.0 * R) / s / 1e9}
+        del t0, t1, i0, i1, acc
+        # config 4's residual evaluation at one GPU's share: 125 000 realisations x 1024 grid points
+        for mode, name in ((mi.MATH_EXACT, "exact"), (mi.MATH_FAST, "fast")):
+            edm = mi.EventDrivenMap(ctx, [13.0589], 125_000, n_grid=1024, math_mode=mode)
+            zd = [0.3310, 0.6914, 1.3557]
+            edm.ComputeF(zd)
+            edm.ComputeF(zd)
+            tmg = edm.last_timings()
+            extra["compute_f_125k_real_1024pts_%s" % name] = {
+                "ms": tmg["total_ms"], "evolve_ms": tmg["evolve_ms"], "restrict_mean_ms": tmg["restrict_mean_ms"],
+                "realisations_per_s": 125_000 / (tmg["total_ms"] * 1e-3),
+                "note": "compute-bound in Evolve (fp32 exp/log/div), not a bandwidth roofline case"}
+            edm.close()
     if world > 1 and not args.no_extra and args.dist_backend == "nccl":
         full = torch.empty(world * nq, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(full, yq)
