@@ -175,47 +175,27 @@ __device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ]
     }
 }
 
-// Vector kernel: each lane streams 16 B (two queries) per step with
-// non-temporal loads/stores (the streams must not evict the table from L2),
-// UNROLL steps per iteration.  Requires xq and yq 16-B aligned.
-template <int MODE, int UNROLL, int FORMULA>
+// Vector kernel: ONE 16-B vector (two queries) per lane and one workgroup per 4 KiB of queries, no
+// grid-stride loop.  Measured on MI355X (profiles/r01_exp_stream_shapes.log): this shape streams 8 B in +
+// 8 B out per element at 6.5 TB/s, a grid capped at 2048 workgroups with a grid-stride loop at 5.0 TB/s.
+// Non-temporal loads/stores: the streams must not evict the table from L2.  Requires xq, yq 16-B aligned.
+template <int MODE, int FORMULA>
 __global__ __launch_bounds__(kBlock) void interp1_vec_kernel(G1Dev g, const double* __restrict__ xq,
                                                              double* __restrict__ yq, size_t nq,
                                                              double extrap)
 {
     const size_t nvec = nq >> 1;
-    const d2* __restrict__ xv = reinterpret_cast<const d2*>(xq);
-    d2* __restrict__ yv = reinterpret_cast<d2*>(yq);
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    // full UNROLL-wide steps
-    for (; i + (size_t)(UNROLL - 1) * stride < nvec; i += (size_t)UNROLL * stride) {
-        double q[2 * UNROLL], r[2 * UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const d2 v = __builtin_nontemporal_load(xv + i + (size_t)u * stride);
-            q[2 * u] = v.x;
-            q[2 * u + 1] = v.y;
-        }
-        eval_batch<MODE, 2 * UNROLL, FORMULA>(g, q, r, extrap);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            d2 v;
-            v.x = r[2 * u];
-            v.y = r[2 * u + 1];
-            __builtin_nontemporal_store(v, yv + i + (size_t)u * stride);
-        }
-    }
-    for (; i < nvec; i += stride) {
-        const d2 v = __builtin_nontemporal_load(xv + i);
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < nvec) {
+        const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2*>(xq) + i);
         double q[2] = {v.x, v.y}, r[2];
         eval_batch<MODE, 2, FORMULA>(g, q, r, extrap);
         d2 o;
         o.x = r[0];
         o.y = r[1];
-        __builtin_nontemporal_store(o, yv + i);
+        __builtin_nontemporal_store(o, reinterpret_cast<d2*>(yq) + i);
     }
-    if ((nq & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    if ((nq & 1) && i == nvec) {      // odd tail element, handled by the first lane past the vectors
         double q[1] = {xq[nq - 1]}, r[1];
         eval_batch<MODE, 1, FORMULA>(g, q, r, extrap);
         yq[nq - 1] = r[0];
@@ -228,8 +208,8 @@ __global__ __launch_bounds__(kBlock) void interp1_scalar_kernel(G1Dev g, const d
                                                                 double* __restrict__ yq, size_t nq,
                                                                 double extrap)
 {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nq; i += stride) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < nq) {
         double q[1] = {xq[i]}, r[1];
         eval_batch<MODE, 1, FORMULA>(g, q, r, extrap);
         yq[i] = r[0];
@@ -241,13 +221,15 @@ mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, const double* xq, double* yq,
 {
     const bool aligned = ((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq)) & 15u) == 0;
     if (aligned) {
-        constexpr int UNROLL = 2;
-        const unsigned grid = mi::stream_grid(ctx, (nq / 2 + UNROLL - 1) / UNROLL, kBlock);
-        hipLaunchKernelGGL((interp1_vec_kernel<MODE, UNROLL, FORMULA>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, xq,
+        const size_t lanes = (nq >> 1) + (nq & 1);                 // one lane per vector (+ one for an odd tail)
+        const size_t grid = (lanes + kBlock - 1) / kBlock;
+        if (grid > 0x7fffffffull) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_interp1_f64_dev: nq=%zu too large for one launch", nq);
+        hipLaunchKernelGGL((interp1_vec_kernel<MODE, FORMULA>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, d, xq,
                            yq, nq, extrap);
     } else {
-        const unsigned grid = mi::stream_grid(ctx, nq, kBlock);
-        hipLaunchKernelGGL((interp1_scalar_kernel<MODE, FORMULA>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, xq, yq,
+        const size_t grid = (nq + kBlock - 1) / kBlock;
+        if (grid > 0x7fffffffull) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_interp1_f64_dev: nq=%zu too large for one launch", nq);
+        hipLaunchKernelGGL((interp1_scalar_kernel<MODE, FORMULA>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, d, xq, yq,
                            nq, extrap);
     }
     MI_LAUNCH_CHECK(ctx, "interp1 kernel");

@@ -201,7 +201,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(ginfo["mode"], args.queries, nq),
-            "kernel": "interp1_vec_kernel<%d,2>" % ginfo["mode"],
+            "kernel": "interp1_vec_kernel<%d,...>" % ginfo["mode"],
             "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
             "note": "achieved = (16 B/query + table bytes) / HIP-event time per launch; traffic: see profiles/",
         },
