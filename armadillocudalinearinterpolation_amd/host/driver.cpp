@@ -1,6 +1,6 @@
 // The reference's fixed problem (Driver.cu:11-126) on the MI355X path: beta = 13.0589, Z0 = (0.3310, 0.6914,
 // 1.3557), Newton tolerance 1e-4, max 10 iterations, forward-difference epsilon 1e-2, damping 1, 512 grid points.
-//   driver [--real R] [--threads N] [--fast] [--debug DIR] [--json FILE] [--quiet]
+//   driver [--real R] [--threads N] [--fast] [--debug DIR] [--json FILE] [--quiet] [--stability]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -9,18 +9,20 @@
 
 #include "event_driven_map.hpp"
 #include "newton_solver.hpp"
+#include "stability.hpp"
 
 int main(int argc, char* argv[])
 {
     unsigned int noReal = 1000;        // Driver.cu:19
     int noThreads = 512;               // Driver.cu:69
-    bool fast = false, quiet = false;
+    bool fast = false, quiet = false, stability = false;
     const char *debug_dir = nullptr, *json = nullptr;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--real") && i + 1 < argc) noReal = std::strtoul(argv[++i], nullptr, 10);
         else if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) noThreads = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--fast")) fast = true;
         else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
+        else if (!std::strcmp(argv[i], "--stability")) stability = true;
         else if (!std::strcmp(argv[i], "--debug") && i + 1 < argc) debug_dir = argv[++i];
         else if (!std::strcmp(argv[i], "--json") && i + 1 < argc) json = argv[++i];
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
@@ -56,6 +58,19 @@ int main(int argc, char* argv[])
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (!quiet) std::cout << "Homogeneous Solution = \n" << solution << std::endl;
 
+    // Driver.cu:46,86-114 (commented there): unstable eigenvalues of the equation-free map at the solution
+    int n_unstable = -1;
+    std::vector<std::complex<double>> eigs;
+    if (stability) {
+        if (debug_dir) event.SetDebugFlag(false);
+        Stability stab(Stability::ProblemType::equationFree, &event);
+        stab.SetFiniteDifferenceEpsilon(pars.finiteDifferenceEpsilon);
+        eigs = stab.ComputeEigenvalues(solution);
+        n_unstable = 0;
+        for (const auto& l : eigs) n_unstable += std::abs(l) > 1.0;
+        if (!quiet) std::cout << "Number of unstable eigenvalues = " << n_unstable << std::endl;
+    }
+
     const bool ok = flag == AbstractNonlinearSolver::ExitFlagType::converged;
     if (json) {
         FILE* fp = std::fopen(json, "w");
@@ -66,6 +81,8 @@ int main(int argc, char* argv[])
                          ok ? "true" : "false", newton.LastIterationCount(), newton.LastResidualEvaluations(), noReal,
                          noThreads, fast ? "fast" : "exact", secs, solution(0), solution(1), solution(2), f0(0), f0(1), f0(2));
             for (int i = 0; i <= newton.LastIterationCount(); ++i) std::fprintf(fp, "%s%.17g", i ? ", " : "", history(i));
+            std::fprintf(fp, "],\n \"n_unstable\": %d, \"eigenvalues\": [", n_unstable);
+            for (size_t i = 0; i < eigs.size(); ++i) std::fprintf(fp, "%s[%.17g, %.17g]", i ? ", " : "", eigs[i].real(), eigs[i].imag());
             std::fprintf(fp, "]}\n");
             std::fclose(fp);
         }

@@ -4,7 +4,12 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <algorithm>
+#include <complex>
+#include <vector>
+
 #include "newton_solver.hpp"
+#include "stability.hpp"
 
 static int failures = 0;
 #define EXPECT(cond)                                                          \
@@ -111,6 +116,50 @@ int main()
         NewtonSolver sb(&b, &guess, &pars);
         sb.Solve(sol, hist, flag);
         EXPECT(flag == AbstractNonlinearSolver::ExitFlagType::converged && sb.LastIterationCount() > full);
+    }
+    {   // eigenvalues: known spectra, complex pairs, defective and larger matrices
+        auto sorted = [](std::vector<std::complex<double>> v) {
+            std::sort(v.begin(), v.end(), [](const std::complex<double>& a, const std::complex<double>& b) {
+                return a.real() != b.real() ? a.real() < b.real() : a.imag() < b.imag(); });
+            return v;
+        };
+        const double rot[4] = {0, 1, -1, 0};                                // [[0,-1],[1,0]] column-major: +-i
+        auto e = sorted(mi355::eig_general(rot, 2));
+        EXPECT(std::abs(e[0] - std::complex<double>(0, -1)) < 1e-14 && std::abs(e[1] - std::complex<double>(0, 1)) < 1e-14);
+        // companion matrix of (x-2)(x^2 - x + 0.5): eigenvalues 2, 0.5 +- 0.5i
+        const double comp[9] = {0, 1, 0, 0, 0, 1, 1.0, -2.5, 3.0};           // columns; last column = -coefficients
+        e = sorted(mi355::eig_general(comp, 3));
+        EXPECT(std::abs(e[0] - std::complex<double>(0.5, -0.5)) < 1e-12 && std::abs(e[1] - std::complex<double>(0.5, 0.5)) < 1e-12 &&
+               std::abs(e[2] - std::complex<double>(2.0, 0.0)) < 1e-12);
+        const double jord[4] = {3, 0, 1, 3};                                   // Jordan block: double eigenvalue 3
+        e = mi355::eig_general(jord, 2);
+        EXPECT(std::abs(e[0] - 3.0) < 1e-7 && std::abs(e[1] - 3.0) < 1e-7);
+        const int n = 6;                                                       // upper-triangular + similarity: spectrum 1..6
+        std::vector<double> A(n * n, 0.0), T(n * n, 0.0), B(n * n, 0.0);
+        for (int j = 0; j < n; ++j) for (int i = 0; i <= j; ++i) A[i + j * n] = (i == j) ? j + 1.0 : 0.3 * (i + 1) - 0.2 * j;
+        for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) T[i + j * n] = (i == j) ? 1.0 : (i > j ? 0.5 / (1 + i - j) : 0.0);   // unit lower
+        // B = T * A * T^-1 ; T^-1 by forward substitution on each unit vector
+        std::vector<double> Ti(n * n, 0.0);
+        for (int c2 = 0; c2 < n; ++c2) for (int i = 0; i < n; ++i) { double s2 = (i == c2); for (int k = 0; k < i; ++k) s2 -= T[i + k * n] * Ti[k + c2 * n]; Ti[i + c2 * n] = s2; }
+        std::vector<double> TA(n * n, 0.0);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) for (int k = 0; k < n; ++k) TA[i + j * n] += T[i + k * n] * A[k + j * n];
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) for (int k = 0; k < n; ++k) B[i + j * n] += TA[i + k * n] * Ti[k + j * n];
+        e = sorted(mi355::eig_general(B.data(), n));
+        for (int i = 0; i < n; ++i) EXPECT(std::abs(e[i] - (double)(i + 1)) < 1e-9);
+        // Stability counts: analytic Jacobian of the toy problem at its root; equationFree adds the identity
+        Toy toy; ToyJac jac;
+        arma::vec root(3);
+        root(0) = r0; root(1) = r1; root(2) = std::exp(-r0);
+        Stability smap(Stability::ProblemType::map, &toy, &jac), sflow(Stability::ProblemType::flow, &toy, &jac),
+                  sef(Stability::ProblemType::equationFree, &toy, &jac), sfd(Stability::ProblemType::map, &toy);
+        // J = [[2r0, 2r1, 0],[r1, r0, 0],[e^-r0, 0, 1]]: eigenvalues 1 and (3r0 +- sqrt(r0^2 + 8 r1^2))/2
+        const double d = std::sqrt(r0 * r0 + 8 * r1 * r1), l1 = 0.5 * (3 * r0 + d), l2 = 0.5 * (3 * r0 - d);
+        EXPECT(smap.ComputeNumUnstableEigenvalues(root) == (l1 > 1) + (l2 > 1));          // |1| is not > 1
+        EXPECT(sflow.ComputeNumUnstableEigenvalues(root) == 3);
+        EXPECT(sef.ComputeNumUnstableEigenvalues(root) == 3);                               // spectrum shifted by +1
+        sfd.SetFiniteDifferenceEpsilon(1e-7);
+        auto efd = sorted(sfd.ComputeEigenvalues(root));
+        EXPECT(std::abs(efd[2].real() - l1) < 1e-5 && std::abs(efd[0].real() - std::min(1.0, l2)) < 1e-5);
     }
     ConvergenceCriterion c(1e-3);
     EXPECT(c.TestConvergence(1e-3) && !c.TestConvergence(1.0000001e-3));     // <=, ConvergenceCriterion.cpp:14

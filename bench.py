@@ -175,7 +175,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max, ev_max = float(t[0]), float(t[1])
 
-    alg_bytes = 16.0 * nq + (16.0 if args.table == "general" else 8.0) * args.ng    # per launch, per GPU
+    # 8 B query in + 8 B result out per query, plus the resident table read once per launch
+    alg_bytes = 16.0 * nq + float(ginfo["table_bytes"])                              # per launch, per GPU
     kernel_s = ev / args.steps                                                        # this rank's avg launch
     achieved = alg_bytes / kernel_s / 1e9
     result = {

@@ -104,8 +104,8 @@ def test_driver_newton_solve_matches_oracle_newton(tmp_path):
     Z0 = [float(np.float32(0.3310)), float(np.float32(0.6914)), float(np.float32(1.3557))]
     # ---- 1024 grid points: converges
     js = os.path.join(tmp_path, "driver1024.json")
-    out = subprocess.run([os.path.join(HOST, "driver"), "--real", "1000", "--threads", "1024", "--json", js],
-                         capture_output=True, text=True)
+    out = subprocess.run([os.path.join(HOST, "driver"), "--real", "1000", "--threads", "1024", "--json", js,
+                          "--stability"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "The method converged after" in out.stdout and "Newton Method" in out.stdout
     r = json.load(open(js))
@@ -120,6 +120,19 @@ def test_driver_newton_solve_matches_oracle_newton(tmp_path):
     assert r["history"][-1] <= 1e-4
     f1024, _ = oracle.edm_compute_f(p, Z0)
     assert np.allclose(r["f0_1024"], f1024, rtol=0, atol=2e-7)
+    # Stability (Stability.cpp:52-111): eigenvalues of I + FD Jacobian at the solution vs numpy on the oracle's
+    us = np.array(r["solution"])
+    f0, d = oracle.edm_compute_f(p, us)
+    J = np.empty((3, 3))
+    for i in range(3):
+        du = us.copy()
+        du[i] += 1e-2
+        df, d = oracle.edm_compute_f(p, du, seed_ind=d["seed_ind"])
+        J[:, i] = (df - f0) * (1e-2) ** -1
+    ev_ref = np.sort_complex(np.linalg.eigvals(J + np.eye(3)))
+    ev = np.sort_complex(np.array([complex(a, b) for a, b in r["eigenvalues"]]))
+    assert np.allclose(ev, ev_ref, rtol=0, atol=1e-3)
+    assert r["n_unstable"] == int(np.sum(np.abs(ev_ref) > 1.0))
     # ---- 512 grid points (Driver.cu:69): not converged after 10 iterations, like the oracle iteration
     js = os.path.join(tmp_path, "driver512.json")
     dbg = os.path.join(tmp_path, "dumps")
