@@ -17,6 +17,7 @@ from ._lib import EdmParams, MiError, check  # noqa: F401
 
 MI_GRID_SANITISE = 0x1
 MI_GRID_DEVICE_PTRS = 0x2
+MI_GRID2_COMPACT = 0x4
 MATH_EXACT = 0
 MATH_FAST = 1
 
@@ -200,15 +201,16 @@ class Grid2:
         return np.ascontiguousarray(z.T).reshape(-1)
 
     @classmethod
-    def from_axes(cls, ctx, x, y, z):
+    def from_axes(cls, ctx, x, y, z, compact=False):
         x, y = _np64(x), _np64(y)
         zc = cls._colmajor(z, y.size, x.size)
         h = C.c_void_p()
-        check(ctx._L.mi_grid2_create(ctx._h, _ptr(x), x.size, _ptr(y), y.size, _ptr(zc), 0, C.byref(h)), ctx._h)
+        check(ctx._L.mi_grid2_create(ctx._h, _ptr(x), x.size, _ptr(y), y.size, _ptr(zc),
+                                     MI_GRID2_COMPACT if compact else 0, C.byref(h)), ctx._h)
         return cls(ctx, h)
 
     @classmethod
-    def uniform(cls, ctx, x0, dx, nx, y0, dy, ny, z):
+    def uniform(cls, ctx, x0, dx, nx, y0, dy, ny, z, compact=False):
         """z: (ny, nx) numpy array, or a column-major float64 CUDA tensor of ny*nx elements."""
         h = C.c_void_p()
         if isinstance(z, np.ndarray) or not hasattr(z, "is_cuda"):
@@ -218,6 +220,8 @@ class Grid2:
             if z.numel() != nx * ny:
                 raise ValueError("Z must have nx*ny elements")
             zc, flags = z, MI_GRID_DEVICE_PTRS
+        if compact:
+            flags |= MI_GRID2_COMPACT
         check(ctx._L.mi_grid2_create_uniform(ctx._h, float(x0), float(dx), nx, float(y0), float(dy), ny,
                                              _ptr(zc), flags, C.byref(h)), ctx._h)
         return cls(ctx, h)

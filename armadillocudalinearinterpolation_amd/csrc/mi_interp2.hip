@@ -1,8 +1,16 @@
-// Scattered bilinear interpolation over an HBM-resident column-major table
-// (arma::mat layout) on MI355X.  Semantics: oracle/interp_oracle.c
-// orc_interp2_bilinear[_uniform]; blend along y (contiguous) inside the two
-// bracketing columns, then along x.  16 B in + 8 B out per query; the table is
-// gathered through L2 / Infinity Cache as two 16-B {Z(l,c), Z(l+1,c)} pairs.
+// Scattered bilinear interpolation over an HBM-resident table (input: column-major
+// arma::mat layout) on MI355X.  Semantics: oracle/interp_oracle.c
+// orc_interp2_bilinear[_uniform]; blend along y inside the two bracketing columns,
+// then along x.  16 B in + 8 B out per query.
+// Resident layouts (the table is far larger than L2, so every gather location is an
+// L2 miss; both put the four corners of a cell in 32 contiguous bytes instead of the
+// two separate 16-B column segments of the arma::mat layout -- measured 4.02 ms ->
+// 2.27 / 2.08 ms for 1e8 queries on 4096^2):
+//   column pairs  element (l,c) = {Z(l,c), Z(l,min(c+1,nx-1))}, 16 B; corners =
+//                 elements (l,c),(l+1,c); 2x the input bytes
+//   quad cells    element (l,c) = {Z(l,c), Z(l,rx), Z(ry,c), Z(ry,rx)}, 32 B, 32-B
+//                 aligned = exactly one 64-B sector per query; 4x the input bytes
+// HBM3E capacity (288 GB) is what makes spending 2-4x on a 128 MiB table sensible.
 // Compiled with -ffp-contract=off (every product/sum rounds separately).
 #include <algorithm>
 #include <cmath>
@@ -21,9 +29,12 @@ struct AxisDev {
     double x0, dx;         // implicit: node_i = fma(i, dx, x0)
 };
 
+typedef double d2v __attribute__((ext_vector_type(2)));
+
 struct G2Dev {
     AxisDev ax, ay;
-    const double* z;       // ny*nx + 1 doubles, column-major
+    const d2v* zp;         // (ny*nx + 1) column pairs {Z(l,c), Z(l,c+1)}, index l + c*ny
+    int quads;             // 1: zp holds 2*ny*nx d2v: cell (l,c) = {Z(l,c), Z(l,rx)}, {Z(ry,c), Z(ry,rx)} (32 B)
 };
 
 struct mi_grid2 {
@@ -38,10 +49,6 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kMaxWalk = 4;
-
-struct __attribute__((packed, aligned(8))) zpair {
-    double a, b;
-};
 
 __device__ __forceinline__ double axis_node(const AxisDev& a, int i)
 {
@@ -79,14 +86,16 @@ __device__ __forceinline__ double eval2(const G2Dev& g, double qx, double qy, do
     const int lx = axis_locate(g.ax, sx), ly = axis_locate(g.ay, sy);
     const int rx = min(lx + 1, g.ax.n - 1), ry = min(ly + 1, g.ay.n - 1);
     const size_t ny = (size_t)g.ay.n;
-    const zpair c0p = *reinterpret_cast<const zpair*>(g.z + (size_t)lx * ny + ly);
-    const zpair c1p = *reinterpret_cast<const zpair*>(g.z + (size_t)rx * ny + ly);
+    const size_t k = (size_t)lx * ny + ly;
+    const d2v* cell = g.quads ? g.zp + 2 * k : g.zp + k;
+    const d2v lo = cell[0];                 // {Z(ly,lx), Z(ly,rx)}
+    const d2v hi = cell[1];                 // pairs: next row (padding past the last); quads: {Z(ry,lx), Z(ry,rx)}
     const double wx = weight(axis_node(g.ax, lx), axis_node(g.ax, rx), sx);
     const double wy = weight(axis_node(g.ay, ly), axis_node(g.ay, ry), sy);
-    const double z01 = (ry != ly) ? c0p.b : c0p.a;
-    const double z11 = (ry != ly) ? c1p.b : c1p.a;
-    const double c0 = (1.0 - wy) * c0p.a + wy * z01;
-    const double c1 = (1.0 - wy) * c1p.a + wy * z11;
+    const double z01 = (ry != ly) ? hi.x : lo.x;
+    const double z11 = (ry != ly) ? hi.y : lo.y;
+    const double c0 = (1.0 - wy) * lo.x + wy * z01;
+    const double c1 = (1.0 - wy) * lo.y + wy * z11;
     const double r = (1.0 - wx) * c0 + wx * c1;
     if (oor) return (qx != qx || qy != qy) ? __builtin_nan("") : extrap;
     return r;
@@ -175,14 +184,76 @@ mi_status make_uniform_axis(mi_ctx* ctx, double x0, double dx, size_t n, const c
     return MI_OK;
 }
 
-mi_status upload_z(mi_ctx* ctx, const double* z, size_t count, bool dev, void** out)
+__global__ __launch_bounds__(kBlock) void quad_cells_kernel(const double* __restrict__ z, size_t ny, size_t nx,
+                                                            d2v* __restrict__ zq)
 {
-    hipError_t e = hipMalloc(out, (count + 1) * sizeof(double));
+    const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;      // k = l + c*ny
+    if (k >= ny * nx) return;
+    const size_t c = k / ny, l = k - c * ny;
+    const size_t dr = (l + 1 < ny) ? 1 : 0, dc = (c + 1 < nx) ? ny : 0;
+    d2v a, b;
+    a.x = z[k];
+    a.y = z[k + dc];
+    b.x = z[k + dr];
+    b.y = z[k + dr + dc];
+    zq[2 * k] = a;
+    zq[2 * k + 1] = b;
+}
+
+__global__ __launch_bounds__(kBlock) void pair_columns_kernel(const double* __restrict__ z, size_t ny, size_t nx,
+                                                              d2v* __restrict__ zp)
+{
+    const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;      // k = l + c*ny
+    const size_t count = ny * nx;
+    if (k < count) {
+        const size_t c = k / ny;
+        d2v v;
+        v.x = z[k];
+        v.y = (c + 1 < nx) ? z[k + ny] : z[k];                       // rx = min(c+1, nx-1)
+        zp[k] = v;
+    } else if (k == count) {
+        d2v v;
+        v.x = 0.0;
+        v.y = 0.0;
+        zp[k] = v;                                                   // padding element (never selected)
+    }
+}
+
+// column-major input (host or device) -> resident column-pair layout
+mi_status upload_z(mi_ctx* ctx, const double* z, size_t ny, size_t nx, bool dev, void** out, bool quads)
+{
+    const size_t count = ny * nx;
+    hipError_t e = hipMalloc(out, (quads ? 2 * count : count + 1) * sizeof(d2v));
     if (e != hipSuccess)
-        return mi::fail(ctx, MI_ERR_NOMEM, "hipMalloc(%zu) for Z failed: %s", (count + 1) * sizeof(double), hipGetErrorString(e));
-    MI_HIP(ctx, hipMemcpy(*out, z, count * sizeof(double), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    MI_HIP(ctx, hipMemset((char*)*out + count * sizeof(double), 0, sizeof(double)));
+        return mi::fail(ctx, MI_ERR_NOMEM, "hipMalloc(%zu) for Z failed: %s", (count + 1) * sizeof(d2v), hipGetErrorString(e));
+    const double* src = z;
+    void* staging = nullptr;
+    if (!dev) {
+        e = hipMalloc(&staging, count * sizeof(double));
+        if (e != hipSuccess) return mi::fail(ctx, MI_ERR_NOMEM, "hipMalloc staging for Z failed: %s", hipGetErrorString(e));
+        MI_HIP(ctx, hipMemcpy(staging, z, count * sizeof(double), hipMemcpyHostToDevice));
+        src = (const double*)staging;
+    }
+    const size_t grid = (count + 1 + kBlock - 1) / kBlock;
+    if (quads)
+        hipLaunchKernelGGL(quad_cells_kernel, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, src, ny, nx, (d2v*)*out);
+    else
+        hipLaunchKernelGGL(pair_columns_kernel, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, src, ny, nx, (d2v*)*out);
+    hipError_t le = hipGetLastError();
+    hipError_t se = hipStreamSynchronize(ctx->stream);
+    if (staging) (void)hipFree(staging);
+    if (le != hipSuccess || se != hipSuccess)
+        return mi::fail(ctx, MI_ERR_HIP, "pair_columns_kernel failed: %s", hipGetErrorString(le != hipSuccess ? le : se));
     return MI_OK;
+}
+
+// Resident layout choice.  Quad cells (32 B per cell, exactly one 64-B sector per query) measured 8 % faster
+// than column pairs (16 B per element, 1.25 sectors per query) on the 4096^2 / 1e8-query config at twice the
+// bytes; they are the default while the table stays under 16 GiB, MI_GRID2_COMPACT forces pairs.
+bool want_quads(unsigned flags, size_t ny, size_t nx)
+{
+    if (flags & MI_GRID2_COMPACT) return false;
+    return (double)ny * (double)nx * 32.0 <= 16.0 * 1024.0 * 1024.0 * 1024.0;
 }
 
 void destroy(mi_grid2* g)
@@ -202,7 +273,7 @@ mi_status mi_grid2_create(mi_ctx* ctx, const double* x, size_t nx, const double*
                           unsigned flags, mi_grid2** out)
 {
     MI_REQUIRE(ctx, ctx && x && y && z && out, "mi_grid2_create: NULL argument");
-    MI_REQUIRE(ctx, (flags & ~MI_GRID_DEVICE_PTRS) == 0, "mi_grid2_create: unknown flags 0x%x", flags);
+    MI_REQUIRE(ctx, (flags & ~(MI_GRID_DEVICE_PTRS | MI_GRID2_COMPACT)) == 0, "mi_grid2_create: unknown flags 0x%x", flags);
     *out = nullptr;
     if (nx < 2 || ny < 2) return mi::fail(ctx, MI_ERR_GRID, "mi_grid2_create: need at least 2x2 nodes");
     MI_REQUIRE(ctx, nx < 0x7ffffff0u && ny < 0x7ffffff0u, "mi_grid2_create: axis too long");
@@ -219,9 +290,11 @@ mi_status mi_grid2_create(mi_ctx* ctx, const double* x, size_t nx, const double*
     g->dev_x = g->dev_y = g->dev_z = nullptr;
     st = make_explicit_axis(ctx, xs, "X", &g->dev_x, &g->d.ax);
     if (st == MI_OK) st = make_explicit_axis(ctx, ys, "Y", &g->dev_y, &g->d.ay);
-    if (st == MI_OK) st = upload_z(ctx, z, nx * ny, dev, &g->dev_z);
+    const bool quads = want_quads(flags, ny, nx);
+    if (st == MI_OK) st = upload_z(ctx, z, ny, nx, dev, &g->dev_z, quads);
+    g->d.quads = quads;
     if (st != MI_OK) { destroy(g); return st; }
-    g->d.z = (const double*)g->dev_z;
+    g->d.zp = (const d2v*)g->dev_z;
     *out = g;
     return MI_OK;
 }
@@ -230,7 +303,7 @@ mi_status mi_grid2_create_uniform(mi_ctx* ctx, double x0, double dx, size_t nx, 
                                   const double* z, unsigned flags, mi_grid2** out)
 {
     MI_REQUIRE(ctx, ctx && z && out, "mi_grid2_create_uniform: NULL argument");
-    MI_REQUIRE(ctx, (flags & ~MI_GRID_DEVICE_PTRS) == 0, "mi_grid2_create_uniform: unknown flags 0x%x", flags);
+    MI_REQUIRE(ctx, (flags & ~(MI_GRID_DEVICE_PTRS | MI_GRID2_COMPACT)) == 0, "mi_grid2_create_uniform: unknown flags 0x%x", flags);
     *out = nullptr;
     if (nx < 2 || ny < 2) return mi::fail(ctx, MI_ERR_GRID, "mi_grid2_create_uniform: need at least 2x2 nodes");
     MI_REQUIRE(ctx, nx < 0x7ffffff0u && ny < 0x7ffffff0u, "mi_grid2_create_uniform: axis too long");
@@ -241,9 +314,11 @@ mi_status mi_grid2_create_uniform(mi_ctx* ctx, double x0, double dx, size_t nx, 
     g->dev_x = g->dev_y = g->dev_z = nullptr;
     mi_status st = make_uniform_axis(ctx, x0, dx, nx, "x", &g->d.ax);
     if (st == MI_OK) st = make_uniform_axis(ctx, y0, dy, ny, "y", &g->d.ay);
-    if (st == MI_OK) st = upload_z(ctx, z, nx * ny, flags & MI_GRID_DEVICE_PTRS, &g->dev_z);
+    const bool quads = want_quads(flags, ny, nx);
+    if (st == MI_OK) st = upload_z(ctx, z, ny, nx, flags & MI_GRID_DEVICE_PTRS, &g->dev_z, quads);
+    g->d.quads = quads;
     if (st != MI_OK) { destroy(g); return st; }
-    g->d.z = (const double*)g->dev_z;
+    g->d.zp = (const d2v*)g->dev_z;
     *out = g;
     return MI_OK;
 }

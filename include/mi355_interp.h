@@ -128,6 +128,9 @@ mi_status mi_interp1_f64(mi_ctx* ctx, const double* x, const double* y, size_t n
  * Z(y_i, x_j).  Blend along y inside the two bracketing columns, then along
  * x (oracle/interp_oracle.c orc_interp2_bilinear).  No counterpart in the
  * reference (BASELINE.json config 3). */
+/* flags: MI_GRID_DEVICE_PTRS (z, x, y are device pointers); MI_GRID2_COMPACT keeps the resident table at 2x the
+ * input bytes (column pairs) instead of the default 4x (quad cells: one 64-B sector per query, ~8 % faster). */
+#define MI_GRID2_COMPACT 0x4u
 mi_status mi_grid2_create(mi_ctx* ctx, const double* x, size_t nx, const double* y, size_t ny,
                           const double* z, unsigned flags, mi_grid2** out);
 mi_status mi_grid2_create_uniform(mi_ctx* ctx, double x0, double dx, size_t nx, double y0, double dy,

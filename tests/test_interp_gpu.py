@@ -66,6 +66,8 @@ def test_bilinear_golden(mi_ctx, golden_dir):
     g = _load(golden_dir, "interp2_bilinear.npz")
     grid = mi.Grid2.from_axes(mi_ctx, g["xg"], g["yg"], g["Z"])
     assert _eq(grid.interp(_t(g["XQ"]), _t(g["YQ"])).cpu().numpy(), g["ZQ"])
+    compact = mi.Grid2.from_axes(mi_ctx, g["xg"], g["yg"], g["Z"], compact=True)      # column-pair layout
+    assert _eq(compact.interp(_t(g["XQ"]), _t(g["YQ"])).cpu().numpy(), g["ZQ"])
     assert _eq(grid.interp_host(g["XQ"], g["YQ"]), g["ZQ"])
     nx, ny = g["xg"].size, g["yg"].size
     gu = mi.Grid2.uniform(mi_ctx, 0.0, 1.0 / (nx - 1), nx, 0.0, 1.0 / (ny - 1), ny, g["Z"])
