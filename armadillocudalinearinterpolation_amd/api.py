@@ -133,6 +133,15 @@ class Grid1:
         return cls(ctx, h)
 
     @classmethod
+    def from_device_nodes(cls, ctx, x, y):
+        """Explicit, strictly increasing abscissae already resident on the device (float64 CUDA tensors)."""
+        if x.numel() != y.numel():
+            raise ValueError("X and Y must have the same number of elements")
+        h = C.c_void_p()
+        check(ctx._L.mi_grid1_create(ctx._h, _ptr(x), _ptr(y), x.numel(), MI_GRID_DEVICE_PTRS, C.byref(h)), ctx._h)
+        return cls(ctx, h)
+
+    @classmethod
     def uniform(cls, ctx, x0, dx, y):
         """Implicit grid X_i = fma(i, dx, x0)."""
         y = _np64(y)

@@ -180,6 +180,43 @@ def test_queries_on_nodes_and_cell_midpoints(mi_ctx):
         assert _eq(grid.interp(_t(q)).cpu().numpy(), oracle.interp1_bracket(X, Y, q))
 
 
+def test_device_resident_table_and_hipgraph_capture(mi_ctx):
+    """Table built from device pointers; the device entry point allocates nothing and never synchronises, so it
+    can be captured into a HIP graph and replayed (mi355_interp.h conventions)."""
+    import armadillocudalinearinterpolation_amd as mi
+    import torch
+    rng = np.random.default_rng(21)
+    X = np.cumsum(rng.random(30000) + 0.01)
+    Y = np.sin(X)
+    grid = mi.Grid1.from_device_nodes(mi_ctx, _t(X), _t(Y))
+    q = rng.random(200001) * (X[-1] - X[0]) + X[0]
+    ref = oracle.interp1_bracket(X, Y, q)
+    assert _eq(grid.interp(_t(q)).cpu().numpy(), ref)
+    with pytest.raises(mi.MiError):
+        mi.Grid1.from_device_nodes(mi_ctx, _t(X[::-1].copy()), _t(Y))          # not increasing
+    # capture on a side stream, replay twice with fresh inputs in the same buffers
+    xq = _t(q)
+    out = torch.zeros_like(xq)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        mi_ctx.use_torch_stream()
+        grid.interp(xq, out=out)                                               # warm-up outside capture
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            mi_ctx.use_torch_stream()
+            grid.interp(xq, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    mi_ctx.use_torch_stream()
+    for seed in (1, 2):
+        q2 = np.random.default_rng(seed).random(q.size) * (X[-1] - X[0]) + X[0]
+        xq.copy_(_t(q2))
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert _eq(out.cpu().numpy(), oracle.interp1_bracket(X, Y, q2))
+
+
 def test_grid_validation_errors(mi_ctx):
     import armadillocudalinearinterpolation_amd as mi
     with pytest.raises(mi.MiError) as e:
