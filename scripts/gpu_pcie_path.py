@@ -1,0 +1,15 @@
+"""Measure the PCIe-inclusive host entry point (mi_interp1_f64_host: H2D + kernel + D2H), 1e8 queries."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle
+import armadillocudalinearinterpolation_amd as mi
+from armadillocudalinearinterpolation_amd import synth
+ctx = mi.Context(0)
+X, Y = synth.config_grid(10**6)
+g = mi.Grid1.from_nodes(ctx, X, Y, sanitise=False)
+q = oracle.splitmix_uniform(0x5EED0003, 10**8)
+g.interp_host(q[:10**6])
+for _ in range(3):
+    t = time.perf_counter(); out = g.interp_host(q); dt = time.perf_counter() - t
+    print("host path 1e8 queries: %.1f ms -> %.3g points/s, %.2f GB/s of PCIe traffic" % (dt * 1e3, 1e8 / dt, 1.6 / dt))
