@@ -105,7 +105,8 @@ __global__ __launch_bounds__(kMaxGrid) void lift_kernel(edm::Model M, SpikeSeeds
 // touches its own slots, so the event loop needs no barrier and the per-neuron
 // loop stays rolled (few VGPRs -> 3 workgroups per CU at N = 1024).
 // LDS per workgroup: w[1024] + 4 waves * (2 or 3) arrays * npl*64 floats.
-template <int MATH, bool HETERO>
+// NS: compile-time bound of the per-bump loops (3 = the reference's noSpikes, else kMaxSpikes)
+template <int MATH, bool HETERO, int NS>
 __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, SpikeSeeds sd,
                                                               const float* __restrict__ v0,
                                                               const float* __restrict__ s0,
@@ -140,10 +141,10 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             if constexpr (HETERO) B[i] = edm::beta_of<MATH>(M.beta_mean, M.beta_sigma, M.seed, M.N, (uint64_t)r + M.real_offset, act ? i : 0u);
         }
         // per-bump event slots ([D2]: start at time 0 / index 0); wave-uniform values
-        float lt[kMaxSpikes], ct[kMaxSpikes];
-        unsigned li[kMaxSpikes], ci[kMaxSpikes];
+        float lt[NS], ct[NS];
+        unsigned li[NS], ci[NS];
 #pragma unroll
-        for (int m = 0; m < kMaxSpikes; ++m) {
+        for (int m = 0; m < NS; ++m) {
             lt[m] = 0.0f;
             ct[m] = 0.0f;
             ci[m] = 0u;
@@ -221,11 +222,11 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             // which bump does the event belong to ([D3]: the reference's increment rule, :625-629)
             unsigned mi = 0;
 #pragma unroll
-            for (int m = 1; m < kMaxSpikes; ++m) {
+            for (int m = 1; m < NS; ++m) {
                 if (m < (int)M.S) {
                     unsigned lmi = li[0];
 #pragma unroll
-                    for (int j = 1; j < kMaxSpikes; ++j) lmi = (mi == (unsigned)j) ? li[j] : lmi;
+                    for (int j = 1; j < NS; ++j) lmi = (mi == (unsigned)j) ? li[j] : lmi;
                     const int dm = abs((int)idx - (int)li[m]);
                     const int d0 = abs((int)idx - (int)lmi);
                     mi += (dm < d0) ? 1u : 0u;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             if (!(crossed & (1u << mi))) {
                 const bool after = now > M.T;
 #pragma unroll
-                for (int m = 0; m < kMaxSpikes; ++m) {
+                for (int m = 0; m < NS; ++m) {
                     if (mi == (unsigned)m) {
                         if (after) { ct[m] = now; ci[m] = idx; }
                         else { lt[m] = now; li[m] = idx; }
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
         }
         // [spike][realisation] layout, EventDrivenMap.cu:661-668
 #pragma unroll
-        for (int m = 0; m < kMaxSpikes; ++m) {
+        for (int m = 0; m < NS; ++m) {
             if (lane == (unsigned)m && m < (int)M.S) {
                 const size_t k = (size_t)m * M.R + r;
                 g_t0[k] = lt[m];
@@ -403,12 +404,13 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd)
     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
     const unsigned cap = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256) * per_cu * 4u;
     if (blocks > cap) blocks = cap;
-    if (hetero)
-        hipLaunchKernelGGL((evolve_kernel<MATH, true>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, e->M, sd,
-                           e->d_v, e->d_s, e->d_w, e->d_t0, e->d_i0, e->d_t1, e->d_i1, e->d_accept);
-    else
-        hipLaunchKernelGGL((evolve_kernel<MATH, false>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, e->M, sd,
-                           e->d_v, e->d_s, e->d_w, e->d_t0, e->d_i0, e->d_t1, e->d_i1, e->d_accept);
+#define MI_EVOLVE(H, NS)                                                                                          \
+    hipLaunchKernelGGL((evolve_kernel<MATH, H, NS>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, e->M, sd, \
+                       e->d_v, e->d_s, e->d_w, e->d_t0, e->d_i0, e->d_t1, e->d_i1, e->d_accept)
+    const bool three = e->p.n_spikes <= 3;
+    if (hetero) { if (three) MI_EVOLVE(true, 3); else MI_EVOLVE(true, kMaxSpikes); }
+    else { if (three) MI_EVOLVE(false, 3); else MI_EVOLVE(false, kMaxSpikes); }
+#undef MI_EVOLVE
     MI_LAUNCH_CHECK(ctx, "evolve kernel");
     return MI_OK;
 }

@@ -80,6 +80,21 @@ def test_compute_f_heterogeneous_beta_bit_parity(mi_ctx):
     assert np.allclose(f, fo, rtol=0, atol=2e-7, equal_nan=True)
 
 
+@pytest.mark.parametrize("Z", [[0.3310, 0.6914], [0.3310, 0.35, 0.6914, 1.0, 1.3557]])
+def test_other_spike_counts(mi_ctx, Z):
+    """noSpikes is a compile-time 3 in the reference (parameters.hpp:12); the path takes 1..8 (generic kernel)."""
+    import armadillocudalinearinterpolation_amd as mi
+    S = len(Z)
+    edm = mi.EventDrivenMap(mi_ctx, [13.0589], 3, n_grid=512, n_spikes=S)
+    f, partial = edm.ComputeF(Z, want_partial=True)
+    dbg = edm.debug_read()
+    p = oracle.edm_default_params(n_grid=512, n_real=3, n_spikes=S)
+    fo, d = oracle.edm_compute_f(p, Z, nthreads=3)
+    for k in ("seed_ind", "v", "s", "t0", "i0", "t1", "i1", "accept", "restricted"):
+        assert np.array_equal(dbg[k], d[k], equal_nan=True), k
+    assert np.allclose(f, fo, rtol=0, atol=2e-7, equal_nan=True)
+
+
 def test_setters_and_second_call(mi_ctx):
     """SetNoThreads(512) then ComputeF (Driver.cu:69-71) and a perturbed Z (finite-difference column)."""
     import armadillocudalinearinterpolation_amd as mi
