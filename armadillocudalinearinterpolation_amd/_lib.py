@@ -69,6 +69,7 @@ SIGNATURES = {
     "mi_interp2_f64_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _dbl]),
     "mi_interp2_f64_host": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _dbl]),
     "mi_restrict_f32_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _vp, _sz]),
+    "mi_restrict_f32_host": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _vp, _sz]),
     "mi_masked_mean_f32_dev": (_i32, [_vp, _vp, _vp, _sz, _sz, _i32, _vp, _vp, _vp]),
     "mi_restrict_mean_f32_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _sz, _sz, _i32,
                                         _vp, _vp, _vp, _vp]),

@@ -226,6 +226,33 @@ mi_status mi_restrict_f32_dev(mi_ctx* ctx, const float* t0, const uint16_t* i0, 
     return MI_OK;
 }
 
+mi_status mi_restrict_f32_host(mi_ctx* ctx, const float* t0, const uint16_t* i0, const float* t1, const uint16_t* i1,
+                               float T, float L, uint32_t ngrid, float* out, size_t n)
+{
+    MI_REQUIRE(ctx, ctx != nullptr, "mi_restrict_f32_host: ctx is NULL");
+    if (n == 0) return MI_OK;
+    MI_REQUIRE(ctx, t0 && i0 && t1 && i1 && out, "mi_restrict_f32_host: NULL array pointer");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    // one scratch slot: [t0 | t1 | i0 | i1], each section 16-byte aligned
+    const size_t fb = (n * sizeof(float) + 15) & ~size_t(15), hb = (n * sizeof(uint16_t) + 15) & ~size_t(15);
+    mi_status st = mi::ensure_scratch(ctx, 0, 2 * fb + 2 * hb);
+    if (st != MI_OK) return st;
+    char* base = (char*)ctx->scratch[0];
+    float* d_t0 = (float*)base;
+    float* d_t1 = (float*)(base + fb);
+    uint16_t* d_i0 = (uint16_t*)(base + 2 * fb);
+    uint16_t* d_i1 = (uint16_t*)(base + 2 * fb + hb);
+    MI_HIP(ctx, hipMemcpyAsync(d_t0, t0, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(ctx, hipMemcpyAsync(d_t1, t1, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(ctx, hipMemcpyAsync(d_i0, i0, n * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(ctx, hipMemcpyAsync(d_i1, i1, n * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    st = mi_restrict_f32_dev(ctx, d_t0, d_i0, d_t1, d_i1, T, L, ngrid, d_t0, n);       // in place, like the reference
+    if (st != MI_OK) return st;
+    MI_HIP(ctx, hipMemcpyAsync(out, d_t0, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+
 mi_status mi_masked_mean_f32_dev(mi_ctx* ctx, const float* x, const uint32_t* accept, size_t nreal, size_t nspikes,
                                  int quirk, float* mean_dev, uint32_t* count_dev, double* sums_dev)
 {

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "mi355_arma.hpp"
 
@@ -45,6 +46,17 @@ int main(int argc, char** argv)
     }
     mi355::interp2(xg, yg, Z, xq, yq, ZI);
     dump(out + "/w_interp2.bin", ZI);
+    // the reference's own interpolation on host vectors (known answer of SURVEY 8c + a small batch)
+    arma::fvec t0(4), t1(4), xr;
+    std::vector<uint16_t> i0 = {512, 100, 1023, 0}, i1 = {514, 101, 1023, 1};
+    t0(0) = 4.f; t1(0) = 6.f; t0(1) = 4.5f; t1(1) = 5.25f; t0(2) = 1.f; t1(2) = 9.f; t0(3) = 4.99f; t1(3) = 5.01f;
+    mi355::restrict_to_horizon(t0, i0, t1, i1, 5.0f, 3.0f, 1024, xr);
+    {
+        FILE* fp = std::fopen((out + "/w_restrict.bin").c_str(), "wb");
+        std::fwrite(xr.memptr(), sizeof(float), xr.n_elem, fp);
+        std::fclose(fp);
+    }
+    if (xr(0) != 0.005859375f) { std::printf("restrict KAT failed: %.9g\n", xr(0)); return 1; }
     // error convention: mismatched sizes throw
     int threw = 0;
     try { arma::vec bad(3); mi355::interp1(X, bad, XI, YI); } catch (const std::exception&) { threw = 1; }

@@ -17,7 +17,9 @@
 #include <cstdlib>
 #include <limits>
 #include <stdexcept>
+#include <cstdint>
 #include <string>
+#include <vector>
 
 #include "mi355_arma_compat.hpp"
 #include "mi355_interp.h"
@@ -109,6 +111,20 @@ inline void interp2(const arma::vec& X, const arma::vec& Y, const arma::mat& Z, 
     mi_status st = mi_interp2_f64_host(dev.get(), g, XI.memptr(), YI.memptr(), ZI.memptr(), XI.n_elem, extrap_val);
     mi_grid2_destroy(g);
     check(st, dev.get(), "mi_interp2_f64_host");
+}
+
+// RestrictKernel (EventDrivenMap.cu:769-785) on host vectors: position at t = final_time from the last event
+// before (t0, i0) and the first event after (t1, i1) the horizon, on the implicit grid x_i = -L + 2L/N * i.
+inline void restrict_to_horizon(const arma::fvec& t0, const std::vector<uint16_t>& i0, const arma::fvec& t1,
+                                const std::vector<uint16_t>& i1, float final_time, float half_length,
+                                unsigned int n_grid, arma::fvec& out, Device& dev = Device::instance())
+{
+    const size_t n = t0.n_elem;
+    if (t1.n_elem != n || i0.size() != n || i1.size() != n) throw std::invalid_argument("restrict_to_horizon(): size mismatch");
+    out.set_size(n);
+    check(mi_restrict_f32_host(dev.get(), t0.memptr(), i0.data(), t1.memptr(), i1.data(), final_time, half_length, n_grid,
+                               out.memptr(), n),
+          dev.get(), "mi_restrict_f32_host");
 }
 
 }  // namespace mi355

@@ -150,6 +150,11 @@ mi_status mi_interp2_f64_host(mi_ctx* ctx, const mi_grid2* g, const double* xq, 
 mi_status mi_restrict_f32_dev(mi_ctx* ctx, const float* t0, const uint16_t* i0, const float* t1,
                               const uint16_t* i1, float final_time, float half_length,
                               uint32_t ngrid, float* out, size_t n);
+/* Host convenience (what the arma::fvec wrapper calls): uploads the four event arrays, runs, downloads
+ * (synchronous).  out may alias t0. */
+mi_status mi_restrict_f32_host(mi_ctx* ctx, const float* t0, const uint16_t* i0, const float* t1,
+                               const uint16_t* i1, float final_time, float half_length, uint32_t ngrid,
+                               float* out, size_t n);
 /* Replaces CountRealisationsKernel + realisationReductionKernelBlocks
  * (EventDrivenMap.cu:787-824): mean over accepted realisations, per spike.
  * x: f32[nspikes*nreal] ([spike][realisation]), accept: u32[nreal] (0/1).

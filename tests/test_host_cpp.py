@@ -51,6 +51,9 @@ def test_arma_wrappers_match_oracle(tmp_path):
     assert np.array_equal(rd("w_interp1.bin"), ref, equal_nan=True)
     assert np.array_equal(rd("w_table_nan.bin"), ref, equal_nan=True)
     assert np.array_equal(rd("w_table_extrap.bin"), oracle.interp1_arma(X, Y, XI, extrap=-1.0))
+    xr = np.fromfile(os.path.join(tmp_path, "w_restrict.bin"), dtype=np.float32)
+    assert np.array_equal(xr, oracle.restrict_f32([4, 4.5, 1, 4.99], [512, 100, 1023, 0], [6, 5.25, 9, 5.01],
+                                                  [514, 101, 1023, 1], 5.0, 3.0, 1024))
     nx, ny, n2 = 40, 25, 20000
     xg = np.array([0.1 * j * (1.0 + 0.01 * j) for j in range(nx)])
     yg = np.array([-1.0 + 0.2 * i for i in range(ny)])
