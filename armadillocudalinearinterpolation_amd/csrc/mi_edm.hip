@@ -572,8 +572,8 @@ mi_status mi_edm_residual_from_sums(const mi_edm_params* p, const double* z, con
     for (uint32_t i = 2; i <= S; ++i) U0[i] = z[i - 1];
     const double count = sc[S];
     for (uint32_t m = 0; m < S; ++m) {
-        // same rounding as the single-device path: fp64 sum -> fp32, fp32 division by the count
-        const float mean = (float)sc[m] / (float)count;
+        // same rounding as the single-device path: fp64 sum / count, rounded to fp32 once
+        const float mean = (float)(sc[m] / count);
         f[m] = (-U0[0] * U0[m + 1] - (double)mean) + U0[0] * (double)p->time_horizon;
     }
     return MI_OK;

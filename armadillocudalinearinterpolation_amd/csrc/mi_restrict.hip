@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void mean_stage2_kernel(const Partials* __r
         // reference quirk: accept[0] holds the count when the mean runs, so
         // realisation 0 is summed iff count == 1 (EventDrivenMap.cu:800-802,:817)
         if (quirk && total == 1u) s += (double)part->x_real0[threadIdx.x];
-        mean[threadIdx.x] = (float)s / (float)total;
+        mean[threadIdx.x] = (float)(s / (double)total);    // one rounding: exact for identical realisations
         if (sums_out) sums_out[threadIdx.x] = s;
         if (threadIdx.x == 0 && count_out) *count_out = total;
     }

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <string>
 
 #include "event_driven_map.hpp"
 #include "newton_solver.hpp"
@@ -54,14 +55,23 @@ int main(int argc, char* argv[])
     arma::vec solution(3), history;
     AbstractNonlinearSolver::ExitFlagType flag;
     const auto t0 = std::chrono::steady_clock::now();
-    newton.Solve(solution, history, flag);                       // Driver.cu:71
+    std::string failure;
+    flag = AbstractNonlinearSolver::ExitFlagType::notConverged;
+    try {
+        newton.Solve(solution, history, flag);                   // Driver.cu:71
+    } catch (const std::exception& e) {
+        // arma::solve throws when the finite-difference Jacobian is singular or NaN (the reference would
+        // terminate here); report it as a failed solve instead of aborting
+        failure = e.what();
+        std::cout << "The method failed: " << failure << std::endl;
+    }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (!quiet) std::cout << "Homogeneous Solution = \n" << solution << std::endl;
 
     // Driver.cu:46,86-114 (commented there): unstable eigenvalues of the equation-free map at the solution
     int n_unstable = -1;
     std::vector<std::complex<double>> eigs;
-    if (stability) {
+    if (stability && failure.empty()) {
         if (debug_dir) event.SetDebugFlag(false);
         Stability stab(Stability::ProblemType::equationFree, &event);
         stab.SetFiniteDifferenceEpsilon(pars.finiteDifferenceEpsilon);
@@ -80,10 +90,11 @@ int main(int argc, char* argv[])
                              " \"f0_1024\": [%.17g, %.17g, %.17g],\n \"history\": [",
                          ok ? "true" : "false", newton.LastIterationCount(), newton.LastResidualEvaluations(), noReal,
                          noThreads, fast ? "fast" : "exact", secs, solution(0), solution(1), solution(2), f0(0), f0(1), f0(2));
-            for (int i = 0; i <= newton.LastIterationCount(); ++i) std::fprintf(fp, "%s%.17g", i ? ", " : "", history(i));
+            const int nh = failure.empty() ? newton.LastIterationCount() + 1 : 0;
+            for (int i = 0; i < nh; ++i) std::fprintf(fp, "%s%.17g", i ? ", " : "", history(i));
             std::fprintf(fp, "],\n \"n_unstable\": %d, \"eigenvalues\": [", n_unstable);
             for (size_t i = 0; i < eigs.size(); ++i) std::fprintf(fp, "%s[%.17g, %.17g]", i ? ", " : "", eigs[i].real(), eigs[i].imag());
-            std::fprintf(fp, "]}\n");
+            std::fprintf(fp, "], \"failure\": \"%s\"}\n", failure.c_str());
             std::fclose(fp);
         }
     }

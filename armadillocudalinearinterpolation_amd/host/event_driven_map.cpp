@@ -177,6 +177,6 @@ void EventDrivenMap::Dump()
     save_column(d + "testAcceptFlag.dat", R, as_float(acc).data());
     save_column(d + "testAverages.dat", SR, xr.data());                         // :485-493: Restrict output
     std::vector<float> mean(S);
-    for (size_t m = 0; m < S; ++m) mean[m] = static_cast<float>(partial_[m]) / static_cast<float>(partial_[S]);
+    for (size_t m = 0; m < S; ++m) mean[m] = static_cast<float>(partial_[m] / partial_[S]);
     save_column(d + "testAveraged.dat", S, mean.data());                        // :495-503
 }

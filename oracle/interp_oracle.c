@@ -338,10 +338,13 @@ void orc_restrict_f32(const float* t0, const uint16_t* i0, const float* t1, cons
  *     `quirk != 0` reproduces the reference's behaviour for comparison.
  *   - the reference accumulates in fp32 in a launch-shape-dependent order
  *     (strided partials + shuffle tree); the sum here is accumulated in fp64
- *     in index order and rounded to fp32 once, then divided in fp32 by
- *     (float)count as at :822.  The HIP path produces the same fp64 sum
- *     bit-for-bit only when its partial sums are exact; tests therefore
- *     compare the mean with a 1-ulp(fp32) tolerance and the count exactly.
+ *     in index order, divided by the count in fp64 and rounded to fp32 ONCE
+ *     (the reference divides two fp32 values, :822).  Rounding once makes the
+ *     mean of identical realisations equal to the common value for every R,
+ *     so a residual sharded over GPUs equals the unsharded one when sigma = 0.
+ *     The HIP path produces the same fp64 sum bit-for-bit only when its
+ *     partial sums are exact; tests therefore compare the mean with a
+ *     1-ulp(fp32) tolerance and the count exactly.
  */
 void orc_masked_mean_f32(const float* x, const uint32_t* accept, size_t nreal, size_t nspikes,
                          int quirk, float* mean, uint32_t* count_out)
@@ -355,7 +358,7 @@ void orc_masked_mean_f32(const float* x, const uint32_t* accept, size_t nreal, s
             if (quirk && r == 0) flag = count;          /* accept[0] holds the count by then */
             if (flag == 1u) acc += (double)x[m * nreal + r];
         }
-        mean[m] = (float)acc / (float)count;
+        mean[m] = (float)(acc / (double)count);
     }
     if (count_out) *count_out = count;
 }

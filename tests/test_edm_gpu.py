@@ -141,3 +141,20 @@ def test_many_realisations_are_identical_when_sigma_is_zero(mi_ctx):
     assert np.array_equal(dbg["t0"].reshape(3, 20000)[:, 0], d["t0"].reshape(3, 2)[:, 0])
     t = edm.last_timings()
     assert t["evolve_ms"] > 0 and t["total_ms"] >= t["evolve_ms"]
+
+
+def test_python_newton_on_gpu_matches_oracle_newton(mi_ctx):
+    """The replicated Newton loop used for multi-GPU runs (newton.py), here on one GPU with 1024 grid points."""
+    import armadillocudalinearinterpolation_amd as mi
+    from armadillocudalinearinterpolation_amd import newton
+    Z0 = [float(np.float32(z)) for z in Z_DRIVER]
+    edm = mi.EventDrivenMap(mi_ctx, [13.0589], 64)
+    pars = newton.ParameterList(tolerance=1e-4, maxIterations=10, printOutput=False, finiteDifferenceEpsilon=1e-2)
+    u, hist, conv, it = newton.NewtonSolver(edm, Z0, pars).Solve()
+
+    class Orc:
+        def ComputeF(self, Z):
+            return oracle.edm_compute_f(oracle.edm_default_params(n_real=1), Z)[0]
+    uo, ho, co, io = newton.NewtonSolver(Orc(), Z0, pars).Solve()
+    assert conv and co and it == io
+    assert np.allclose(u, uo, rtol=0, atol=1e-4) and np.allclose(hist, ho, rtol=0, atol=5e-6)

@@ -51,6 +51,10 @@ def _worker(rank, world, port, q):
     try:
         sr = sharding.ShardedResidual(KW["n_real"], _local, _finish)
         f = sr.ComputeF(Z)
+        # the replicated Newton loop over the sharded residual (config 5's structure), 2 iterations
+        from armadillocudalinearinterpolation_amd import newton
+        pars = newton.ParameterList(tolerance=1e-12, maxIterations=2, printOutput=False, finiteDifferenceEpsilon=1e-2)
+        u, hist, conv, it = newton.NewtonSolver(sr, Z, pars).Solve()
         # query sharding + all-gather reassembly of an interp1 result
         X = np.linspace(0, 1, 257)
         Y = np.sin(5 * X)
@@ -59,7 +63,7 @@ def _worker(rank, world, port, q):
         local = torch.from_numpy(oracle.interp1_bracket(X, Y, xi[lo:hi]))
         sizes = [b - a for a, b in (sharding.shard_bounds(xi.size, r, world) for r in range(world))]
         full = sharding.all_gather_results(local, sizes).numpy()
-        q.put((rank, f, full))
+        q.put((rank, f, full, u, hist))
     finally:
         dist.destroy_process_group()
 
@@ -81,7 +85,16 @@ def test_world2_gloo_residual_and_allgather():
     f_ref, d = oracle.edm_compute_f(pf, Z)
     X = np.linspace(0, 1, 257)
     whole = oracle.interp1_bracket(X, np.sin(5 * X), oracle.splitmix_uniform(9, 1001))
-    for rank, f, full in out:
+    # single-process Newton on the unsharded oracle residual
+    from armadillocudalinearinterpolation_amd import newton
+
+    class Whole:
+        def ComputeF(self, Zv):
+            return oracle.edm_compute_f(pf, Zv)[0]
+    pars = newton.ParameterList(tolerance=1e-12, maxIterations=2, printOutput=False, finiteDifferenceEpsilon=1e-2)
+    u_ref, hist_ref, _, _ = newton.NewtonSolver(Whole(), Z, pars).Solve()
+    for rank, f, full, u, hist in out:
         assert np.allclose(f, f_ref, rtol=0, atol=2e-7), (rank, f, f_ref)
         assert np.array_equal(full, whole)
+        assert np.allclose(u, u_ref, rtol=0, atol=1e-5) and np.allclose(hist, hist_ref, rtol=0, atol=1e-5)
     assert np.array_equal(out[0][1], out[1][1])          # every rank holds the same residual
