@@ -175,30 +175,55 @@ __device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ]
     }
 }
 
-// Vector kernel: ONE 16-B vector (two queries) per lane and one workgroup per 4 KiB of queries, no
-// grid-stride loop.  Measured on MI355X (profiles/r01_exp_stream_shapes.log): this shape streams 8 B in +
+// Vector kernel: a fixed VPL = 2 16-B vectors (four queries) per lane and one workgroup per 8 KiB of
+// queries, no grid-stride loop.  Measured on MI355X (profiles/r01_exp_stream_shapes.log): this shape streams 8 B in +
 // 8 B out per element at 6.5 TB/s, a grid capped at 2048 workgroups with a grid-stride loop at 5.0 TB/s.
 // Non-temporal loads/stores: the streams must not evict the table from L2.  Requires xq, yq 16-B aligned.
+#ifndef MI_INTERP1_VPL
+#define MI_INTERP1_VPL 2     // 16-B vectors per lane: 1 / 2 / 4 measured 0.276 / 0.250 / 0.253 ms (sorted), random unchanged
+#endif
 template <int MODE, int FORMULA>
 __global__ __launch_bounds__(kBlock) void interp1_vec_kernel(G1Dev g, const double* __restrict__ xq,
                                                              double* __restrict__ yq, size_t nq,
                                                              double extrap)
 {
+    constexpr int VPL = MI_INTERP1_VPL;
     const size_t nvec = nq >> 1;
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < nvec) {
-        const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2*>(xq) + i);
-        double q[2] = {v.x, v.y}, r[2];
-        eval_batch<MODE, 2, FORMULA>(g, q, r, extrap);
-        d2 o;
-        o.x = r[0];
-        o.y = r[1];
-        __builtin_nontemporal_store(o, reinterpret_cast<d2*>(yq) + i);
-    }
-    if ((nq & 1) && i == nvec) {      // odd tail element, handled by the first lane past the vectors
-        double q[1] = {xq[nq - 1]}, r[1];
-        eval_batch<MODE, 1, FORMULA>(g, q, r, extrap);
-        yq[nq - 1] = r[0];
+    const size_t base = (size_t)blockIdx.x * (kBlock * VPL) + threadIdx.x;
+    double q[2 * VPL], r[2 * VPL];
+    bool full = base + (size_t)(VPL - 1) * kBlock < nvec;
+    if (full) {
+#pragma unroll
+        for (int u = 0; u < VPL; ++u) {
+            const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2*>(xq) + base + (size_t)u * kBlock);
+            q[2 * u] = v.x;
+            q[2 * u + 1] = v.y;
+        }
+        eval_batch<MODE, 2 * VPL, FORMULA>(g, q, r, extrap);
+#pragma unroll
+        for (int u = 0; u < VPL; ++u) {
+            d2 o;
+            o.x = r[2 * u];
+            o.y = r[2 * u + 1];
+            __builtin_nontemporal_store(o, reinterpret_cast<d2*>(yq) + base + (size_t)u * kBlock);
+        }
+    } else {
+        for (int u = 0; u < VPL; ++u) {
+            const size_t i = base + (size_t)u * kBlock;
+            if (i < nvec) {
+                const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2*>(xq) + i);
+                double q1[2] = {v.x, v.y}, r1[2];
+                eval_batch<MODE, 2, FORMULA>(g, q1, r1, extrap);
+                d2 o;
+                o.x = r1[0];
+                o.y = r1[1];
+                __builtin_nontemporal_store(o, reinterpret_cast<d2*>(yq) + i);
+            } else if ((nq & 1) && i == nvec) {   // odd tail element, handled by the first lane past the vectors
+                double q1[1] = {xq[nq - 1]}, r1[1];
+                eval_batch<MODE, 1, FORMULA>(g, q1, r1, extrap);
+                yq[nq - 1] = r1[0];
+            }
+        }
     }
 }
 
@@ -222,7 +247,8 @@ mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, const double* xq, double* yq,
     const bool aligned = ((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq)) & 15u) == 0;
     if (aligned) {
         const size_t lanes = (nq >> 1) + (nq & 1);                 // one lane per vector (+ one for an odd tail)
-        const size_t grid = (lanes + kBlock - 1) / kBlock;
+        const size_t per_block = (size_t)kBlock * MI_INTERP1_VPL;
+        const size_t grid = (lanes + per_block - 1) / per_block;
         if (grid > 0x7fffffffull) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_interp1_f64_dev: nq=%zu too large for one launch", nq);
         hipLaunchKernelGGL((interp1_vec_kernel<MODE, FORMULA>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, d, xq,
                            yq, nq, extrap);
