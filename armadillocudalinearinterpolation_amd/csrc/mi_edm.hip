@@ -100,6 +100,33 @@ __global__ __launch_bounds__(kMaxGrid) void lift_kernel(edm::Model M, SpikeSeeds
     s[i] = ss;
 }
 
+// Wave64 unsigned minimum with DPP row shifts + row broadcasts (gfx9 family), result broadcast to every lane.
+// No LDS traffic and no s_waitcnt, unlike __shfl_xor (ds_bpermute_b32).
+__device__ __forceinline__ unsigned wave_umin(unsigned v)
+{
+#define MI_DPP_MIN(ctrl, row_mask) \
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, ctrl, row_mask, 0xf, false))
+    MI_DPP_MIN(0x111, 0xf);   // row_shr:1
+    MI_DPP_MIN(0x112, 0xf);   // row_shr:2
+    MI_DPP_MIN(0x114, 0xf);   // row_shr:4
+    MI_DPP_MIN(0x118, 0xf);   // row_shr:8   -> lane 15 of every row holds its row's minimum
+    MI_DPP_MIN(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    MI_DPP_MIN(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave minimum
+#undef MI_DPP_MIN
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Lexicographic (time, index) minimum over the wave ([D1]).  Times are >= 0 (|t|, 100 or +inf, never NaN), so
+// their bit patterns order like unsigned integers: two unsigned reductions give exactly the same pair as a
+// comparison tree.
+__device__ __forceinline__ void wave_argmin(float& best, unsigned& idx)
+{
+    const unsigned tb = __float_as_uint(best);
+    const unsigned tmin = wave_umin(tb);
+    idx = wave_umin(tb == tmin ? idx : 0xFFFFFFFFu);
+    best = __uint_as_float(tmin);
+}
+
 // ---- EvolveKernel (EventDrivenMap.cu:575-674): one wave64 per realisation ----
 // Neuron state lives in LDS, [wave][array][k*64 + lane]: every lane only ever
 // touches its own slots, so the event loop needs no barrier and the per-neuron
@@ -182,12 +209,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                     if (tau < best || (tau == best && i < idx)) { best = tau; idx = i; }
                 }
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float ot = __shfl_xor(best, off, 64);
-                const unsigned oi = __shfl_xor(idx, off, 64);
-                if (ot < best || (ot == best && oi < idx)) { best = ot; idx = oi; }
-            }
+            wave_argmin(best, idx);
             const float dt = best;
             // analytic state advance (EventDrivenMap.cu:612-617), fused with the firing test for the NEXT event
             const float e1 = edm::expf_<MATH>(-dt);
