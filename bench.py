@@ -222,7 +222,15 @@ def main():
         for name, g, q in (("general_sorted", grid, xs), ("uniform_random", gu, xq), ("uniform_sorted", gu, xs)):
             s = quick(lambda: g.interp(q, out=yq))
             extra[name] = {"ms": s * 1e3, "points_per_s": nq / s, "frac_of_8TBps": 16.0 * nq / s / 1e9 / HBM_PEAK_GBPS}
-        del xs
+        # BASELINE.md section 2's non-uniform variant: X_i = (i + 0.5 u_i)/NG (seed 0x5EED0002), explicit {x,y} table
+        un = synth.splitmix_uniform(0x5EED0002, args.ng, torch.device("cpu")).numpy()
+        Xn = (np.arange(args.ng) + 0.5 * un) / args.ng
+        gn = mi.Grid1.from_nodes(ctx, Xn, Y, sanitise=False)
+        for name, q in (("nonuniform_grid_random", xq), ("nonuniform_grid_sorted", xs)):
+            s = quick(lambda: gn.interp(q, out=yq))
+            extra[name] = {"ms": s * 1e3, "points_per_s": nq / s, "table_mode": gn.info()["mode"],
+                           "frac_of_8TBps": (16.0 * nq + gn.info()["table_bytes"]) / s / 1e9 / HBM_PEAK_GBPS}
+        del xs, gn
         s = quick(lambda: yq.copy_(xq))
         extra["torch_copy_same_bytes"] = {"ms": s * 1e3, "GBps": 16.0 * nq / s / 1e9}
         # config 3: 4096^2 table, 1e8 scattered queries
