@@ -34,6 +34,7 @@ class EdmParams(C.Structure):
         ("seed", C.c_uint64),
         ("math_mode", C.c_int),
         ("mean_quirk", C.c_int),
+        ("max_events", C.c_uint32),
         ("real_offset", C.c_uint32),
     ]
 

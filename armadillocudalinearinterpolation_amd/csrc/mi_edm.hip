@@ -30,6 +30,11 @@ namespace {
 constexpr int kMaxSpikes = 8;
 constexpr int kMaxGrid = 1024;
 constexpr int kEvolveBlock = 256;   // 4 waves = 4 realisations per workgroup
+// Hard bound on events per realisation (mi_edm_params.max_events, default 2^20, at most 2^24): the reference's
+// loop (EventDrivenMap.cu:601) relies on time advancing, which degenerate parameters defeat (a strongly excitatory
+// kernel fires at ever shorter intervals).  Every wave must reach an exit, so the loop also stops after
+// max_events events (the realisation is then simply not accepted); the oracle applies the same rule.
+constexpr unsigned kMaxEventsLimit = 1u << 24;
 #ifndef MI_EVOLVE_UNROLL
 #define MI_EVOLVE_UNROLL 1           // state-pass unroll (measured: see DESIGN.md)
 #endif
@@ -196,7 +201,9 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 else if (base_t == INFINITY) { base_t = edm::kNever; base_i = i; }
             }
         }
-        while (crossed < full && now < two_T) {
+        unsigned events = 0;
+        while (crossed < full && now < two_T && events < M.max_events) {
+            ++events;
             float best = base_t;
             unsigned idx = base_i;
             while (__any(pend != 0u)) {
@@ -332,6 +339,10 @@ mi_status validate(const mi_ctx* ctx, const mi_edm_params* p)
     if (!(p->time_horizon > 0.0f)) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: time_horizon must be > 0");
     if (!(p->beta_stddev >= 0.0f)) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: beta_stddev must be >= 0");
     if (!(p->newton_tol >= 0.0)) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: newton_tol must be >= 0");
+    if (p->max_events < 1 || p->max_events > kMaxEventsLimit)
+        return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: max_events=%u not in [1, 2^24]", p->max_events);
+    if (p->newton_max_iter > 100000u)
+        return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: newton_max_iter=%u exceeds 100000", p->newton_max_iter);
     if (p->math_mode != MI_EDM_MATH_EXACT && p->math_mode != MI_EDM_MATH_FAST)
         return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_edm: unknown math_mode %d", p->math_mode);
     if ((uint64_t)p->n_spikes * p->n_real > 0xfffffff0ull)
@@ -351,6 +362,7 @@ void fill_model(const mi_edm_params& p, edm::Model* M)
     M->beta_mean = p.beta_mean; M->beta_sigma = p.beta_stddev;
     M->seed = p.seed;
     M->real_offset = p.real_offset;
+    M->max_events = p.max_events;
 }
 
 void free_real_buffers(mi_edm* e)
@@ -485,6 +497,7 @@ void mi_edm_default_params(mi_edm_params* p)
     p->seed = 0x5EED0005ull;
     p->math_mode = MI_EDM_MATH_EXACT;
     p->mean_quirk = 0;
+    p->max_events = 1u << 20;
     p->real_offset = 0;
 }
 

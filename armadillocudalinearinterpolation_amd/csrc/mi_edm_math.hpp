@@ -146,6 +146,7 @@ struct Model {
     float beta_mean, beta_sigma;
     uint64_t seed;
     uint32_t real_offset;
+    uint32_t max_events;
 };
 
 struct FdF {

@@ -20,6 +20,8 @@
  *     EventDrivenMap.cu:18-54; the C++ wrapper restores that behaviour).
  *   - mi_last_error(ctx) returns the message of the last failure on that
  *     context (or on the calling thread when ctx is NULL).
+ *   - a context is not thread-safe (one host thread per context, like the
+ *     reference's single-threaded driver); use one context per thread/stream.
  *   - "dev" pointers are HBM addresses valid on the context's device; "host"
  *     pointers are ordinary host memory.  Device entry points are
  *     asynchronous on the context's stream and perform no allocation, copy or
@@ -84,12 +86,13 @@ mi_status mi_timer_elapsed_ms(mi_timer* t, float* ms);
 /* ---- 1-D tables ---------------------------------------------------------
  * General grid: explicit abscissae, the arma::interp1(X, Y, XI, YI) shape.
  * x/y are HOST pointers (n doubles each); the table is uploaded once and
- * stays resident in HBM as interleaved {x,y} nodes.
+ * stays resident in HBM: as Y only when a closed form (linspace-like grids)
+ * reproduces every abscissa bit for bit, else as interleaved {x,y} nodes.
  * flags: MI_GRID_SANITISE    sort + de-duplicate X first (what arma::interp1
  *                            does unless the method is "*linear"); without it
  *                            X must be strictly increasing or MI_ERR_GRID.
- *        MI_GRID_DEVICE_PTRS x/y are device pointers (strictly increasing
- *                            required; validated on device).
+ *        MI_GRID_DEVICE_PTRS x/y are device pointers (copied to the host once
+ *                            for validation and index construction).
  */
 #define MI_GRID_SANITISE     0x1u
 #define MI_GRID_DEVICE_PTRS  0x2u
@@ -100,9 +103,11 @@ mi_status mi_grid1_create(mi_ctx* ctx, const double* x, const double* y, size_t 
 mi_status mi_grid1_create_uniform(mi_ctx* ctx, double x0, double dx, const double* y, size_t n,
                                   unsigned flags, mi_grid1** out);
 mi_status mi_grid1_destroy(mi_grid1* g);
-/* number of nodes after sanitising; search mode chosen at build time
- * (0 = implicit uniform, 1 = explicit nodes + analytic guess,
- *  2 = explicit nodes + bucket index) */
+/* number of nodes after sanitising; table mode chosen at build time
+ * (0 = Y only, abscissae from a closed form -- declared by
+ *      mi_grid1_create_uniform or detected on an explicit grid,
+ *  1 = explicit {x,y} nodes + analytic guess,
+ *  2 = explicit {x,y} nodes + bucket index) */
 mi_status mi_grid1_info(const mi_grid1* g, size_t* n_nodes, int* mode, size_t* table_bytes);
 
 /* ---- 1-D interpolation: the hot path -----------------------------------
@@ -191,6 +196,8 @@ typedef struct mi_edm_params {
     uint64_t seed;                     /* mSeed                                  */
     int math_mode;                     /* MI_EDM_MATH_EXACT or MI_EDM_MATH_FAST  */
     int mean_quirk;                    /* reproduce the accept[0] clobber        */
+    uint32_t max_events;               /* hard bound on events per realisation
+                                          (termination guarantee; default 2^20)  */
     uint32_t real_offset;              /* global index of this shard's first
                                           realisation (multi-GPU sharding; only
                                           enters the per-neuron beta draw)       */

@@ -47,6 +47,7 @@ typedef struct orc_edm_params {
     uint64_t seed;
     int math_mode;
     int mean_quirk;
+    uint32_t max_events;
     uint32_t real_offset;
 } orc_edm_params;
 
@@ -334,7 +335,8 @@ void orc_edm_evolve_one(const orc_edm_params* P, const float* v0, const float* s
     const uint32_t full = (1u << S) - 1u;
     uint32_t crossed = 0, events = 0;
     float now = 0.0f;
-    while (crossed < full && now < 2.0f * T) {
+    /* hard event cap (same rule as the HIP kernel): termination even when time cannot advance */
+    while (crossed < full && now < 2.0f * T && events < P->max_events) {
         float best = INFINITY;
         uint32_t idx = 0;
         for (uint32_t i = 0; i < N; ++i) {
@@ -469,5 +471,5 @@ void orc_edm_default_params(orc_edm_params* p)
     p->vth = 1.0f; p->a1 = 11.0f; p->a2 = 7.0f; p->b1 = 5.0f; p->b2 = 3.5f; p->I = 0.9f; p->L = 3.0f;
     p->newton_tol = 1e-6; p->newton_max_iter = 100; p->n_spikes = 3; p->time_horizon = 5.0f;
     p->n_grid = 1024; p->n_real = 1000; p->beta_mean = 13.0589f; p->beta_stddev = 0.0f;
-    p->seed = 0x5EED0005ull; p->math_mode = 0; p->mean_quirk = 0; p->real_offset = 0;
+    p->seed = 0x5EED0005ull; p->math_mode = 0; p->mean_quirk = 0; p->max_events = 1u << 20; p->real_offset = 0;
 }

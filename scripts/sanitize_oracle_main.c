@@ -15,7 +15,7 @@ void orc_restrict_f32(const float*, const uint16_t*, const float*, const uint16_
 void orc_masked_mean_f32(const float*, const uint32_t*, size_t, size_t, int, float*, uint32_t*);
 void orc_splitmix_uniform(uint64_t, double*, size_t);
 typedef struct { float vth, a1, a2, b1, b2, I, L; double newton_tol; uint32_t newton_max_iter, n_spikes; float time_horizon;
-                 uint32_t n_grid, n_real; float beta_mean, beta_stddev; uint64_t seed; int math_mode, mean_quirk; uint32_t real_offset; } P;
+                 uint32_t n_grid, n_real; float beta_mean, beta_stddev; uint64_t seed; int math_mode, mean_quirk; uint32_t max_events, real_offset; } P;
 void orc_edm_default_params(P*);
 int orc_edm_compute_f(const P*, const double*, double*, uint16_t*, float*, float*, float*, float*, uint16_t*, float*, uint16_t*,
                       uint32_t*, float*, double*, int);

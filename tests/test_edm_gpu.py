@@ -95,6 +95,27 @@ def test_other_spike_counts(mi_ctx, Z):
     assert np.allclose(f, fo, rtol=0, atol=2e-7, equal_nan=True)
 
 
+@pytest.mark.parametrize("kw", [dict(vth=0.0), dict(vth=-1.0), dict(I=1.5), dict(beta_mean=1.0), dict(beta_mean=0.0),
+                                dict(time_horizon=1e-3), dict(a1=0.0, a2=0.0), dict(newton_max_iter=0),
+                                dict(newton_tol=0.0), dict(time_horizon=40.0), dict(I=0.999),
+                                dict(a1=50.0, max_events=3000)])      # runaway excitation: only the event cap ends it
+def test_pathological_parameters_terminate_and_match(mi_ctx, kw):
+    """Degenerate models (division by zero in 1-beta, non-positive threshold, no coupling, zero Newton budget,
+    long horizons ...): the kernel must terminate (bounded event loop, every wave reaches its exit) and still
+    reproduce the oracle bit for bit, NaNs and rejected realisations included."""
+    import armadillocudalinearinterpolation_amd as mi
+    ov = dict(kw)
+    bm = ov.pop("beta_mean", 13.0589)
+    edm = mi.EventDrivenMap(mi_ctx, [bm], 2, n_grid=512, **ov)
+    f, partial = edm.ComputeF(Z_DRIVER, want_partial=True)
+    dbg = edm.debug_read()
+    p = oracle.edm_default_params(n_grid=512, n_real=2, **kw)
+    fo, d = oracle.edm_compute_f(p, Z_DRIVER, nthreads=2)
+    for k in ("v", "s", "t0", "i0", "t1", "i1", "accept"):
+        assert np.array_equal(dbg[k], d[k], equal_nan=True), (kw, k)
+    assert np.array_equal(np.isnan(f), np.isnan(fo)) and np.allclose(f, fo, rtol=0, atol=2e-7, equal_nan=True)
+
+
 def test_setters_and_second_call(mi_ctx):
     """SetNoThreads(512) then ComputeF (Driver.cu:69-71) and a perturbed Z (finite-difference column)."""
     import armadillocudalinearinterpolation_amd as mi
