@@ -236,9 +236,11 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 const float so = S[i];
                 float vv = V[i] * e1;
                 vv = vv + (M.I * (1.0f - e1) + edm::div_<MATH>(so * e1, 1.0f - bk) * (e2 - 1.0f));
-                vv = vv * ((i != idx) ? 1.0f : 0.0f);
+                // reset of the neuron that fired (:615 multiplies every v by (tid != index)): x*1 == x, so only
+                // the slice that holds idx needs the multiply
+                if (k == (idx >> 6)) vv = vv * ((i != idx) ? 1.0f : 0.0f);
                 float sn = so * e3;
-                const unsigned dist = (i >= idx) ? (i - idx) : (idx - i);
+                const unsigned dist = (unsigned)abs((int)i - (int)idx);
                 sn = sn + bk * w_lds[dist & (kMaxGrid - 1)];
                 V[i] = vv;
                 S[i] = sn;
