@@ -51,6 +51,7 @@ SIGNATURES = {
     "mi_ctx_destroy": (_i32, [_vp]),
     "mi_ctx_set_stream": (_i32, [_vp, _vp]),
     "mi_ctx_synchronize": (_i32, [_vp]),
+    "mi_ctx_set_query_order": (_i32, [_vp, _i32]),
     "mi_ctx_device_info": (_i32, [_vp, C.c_char_p, _sz, C.POINTER(_i32), C.POINTER(_sz)]),
     "mi_timer_create": (_i32, [_vp, _pp]),
     "mi_timer_destroy": (_i32, [_vp]),

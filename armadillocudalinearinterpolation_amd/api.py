@@ -64,6 +64,10 @@ class Context:
     def synchronize(self):
         check(self._L.mi_ctx_synchronize(self._h), self._h)
 
+    def set_query_order(self, order):
+        """0 auto (device-side probe), 1 queries are unordered, 2 queries are ordered/clustered."""
+        check(self._L.mi_ctx_set_query_order(self._h, int(order)), self._h)
+
     def device_info(self):
         name = C.create_string_buffer(128)
         cus, hbm = C.c_int(0), C.c_size_t(0)

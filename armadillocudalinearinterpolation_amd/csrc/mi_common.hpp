@@ -25,6 +25,9 @@ struct mi_ctx {
     // that device entry points never allocate
     void* reduce_ws = nullptr;
     static constexpr size_t kReduceWsBytes = 192 * 1024;
+    // three ints inside the workspace: constant 0, constant 1, and the query-order probe's verdict
+    static constexpr size_t kFlagOffset = 176 * 1024;
+    int query_order = 0;         // MI_QUERIES_AUTO / _RANDOM / _ORDERED (mi_ctx_set_query_order)
 };
 
 struct mi_timer {

@@ -73,7 +73,23 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
         return mi::fail(nullptr, MI_ERR_NOMEM, "mi_ctx_create: hipMalloc of the reduction workspace failed: %s",
                         hipGetErrorString(e));
     }
+    const int consts[3] = {0, 1, 0};
+    e = hipMemcpy(static_cast<char*>(c->reduce_ws) + mi_ctx::kFlagOffset, consts, sizeof(consts), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(c->reduce_ws);
+        delete c;
+        return mi::fail(nullptr, MI_ERR_HIP, "mi_ctx_create: workspace initialisation failed: %s", hipGetErrorString(e));
+    }
     *out = c;
+    return MI_OK;
+}
+
+mi_status mi_ctx_set_query_order(mi_ctx* ctx, int order)
+{
+    MI_REQUIRE(ctx, ctx != nullptr, "mi_ctx_set_query_order: ctx is NULL");
+    MI_REQUIRE(ctx, order == MI_QUERIES_AUTO || order == MI_QUERIES_RANDOM || order == MI_QUERIES_ORDERED,
+               "mi_ctx_set_query_order: unknown value %d", order);
+    ctx->query_order = order;
     return MI_OK;
 }
 

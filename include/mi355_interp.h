@@ -71,6 +71,14 @@ mi_status mi_ctx_set_stream(mi_ctx* ctx, void* stream);
 mi_status mi_ctx_synchronize(mi_ctx* ctx);
 const char* mi_last_error(const mi_ctx* ctx);
 int mi_abi_version(void);
+/* Hint about the order of the query vectors handed to mi_interp1_f64_dev on this context.  Unordered queries
+ * over a table larger than L2 are processed by a "region sweep" kernel (workgroup-local ordering by table region
+ * in LDS; results keep the caller's order), ordered/clustered ones by the plain streaming kernel.  AUTO decides on
+ * the device with a 1024-sample probe (no host synchronisation); the other values skip the probe. */
+#define MI_QUERIES_AUTO    0
+#define MI_QUERIES_RANDOM  1
+#define MI_QUERIES_ORDERED 2
+mi_status mi_ctx_set_query_order(mi_ctx* ctx, int order);
 /* name / CU count of the context's device (for bench reports) */
 mi_status mi_ctx_device_info(mi_ctx* ctx, char* name, size_t name_len, int* compute_units,
                              size_t* hbm_bytes);

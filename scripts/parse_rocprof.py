@@ -56,29 +56,43 @@ def main():
     summary["pmc"] = pm
     # HBM traffic of the interp1 kernel per launch, MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are
     # in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads -> x2.
+    # the dominant interp1 kernel of the run (region-sweep or streaming), by average duration
+    dom = [k for k in summary["kernels"] if "interp1_sweep_kernel" in k or "interp1_vec_kernel" in k]
+    dom = max(dom, key=lambda k: summary["kernels"][k]["avg_us"]) if dom else None
+    queries = sys.argv[3] if len(sys.argv) > 3 else "random"
+    nq = int(sys.argv[4]) if len(sys.argv) > 4 else 100000000
     for k, cs in pm.items():
-        if "interp1" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        if k == dom and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             f, w = cs["FETCH_SIZE"]["per_dispatch_median"], cs["WRITE_SIZE"]["per_dispatch_median"]
+            # calibration on the known byte count of this access pattern: the query stream is nq*8 bytes read as
+            # 128-B requests (tallied at 64 B: half of it is missing from FETCH_SIZE); what is left of FETCH_SIZE
+            # is table-gather misses, 64-B requests tallied in full (TCC_EA0_RDREQ and TCC_MISS agree, see README)
+            stream = nq * 8.0
             summary.setdefault("traffic", {})[k] = {
                 "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                 "hbm_bytes_per_launch_raw": (f + w) * 1024.0,
-                "hbm_bytes_per_launch_corrected": (2.0 * f + w) * 1024.0,
-                "note": "corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts 128-B read requests "
-                        "as 64 B (exact for the 16 B/lane query stream; the table-gather share is uncalibrated and "
-                        "may be over-corrected)"}
+                "hbm_bytes_per_launch_doubled": (2.0 * f + w) * 1024.0,
+                "hbm_bytes_per_launch_calibrated": f * 1024.0 + 0.5 * stream + w * 1024.0,
+                "table_gather_bytes_beyond_l2": max(0.0, f * 1024.0 - 0.5 * stream),
+                "note": "doubled = (2*FETCH_SIZE + WRITE_SIZE)*1024 (every read taken as a 128-B request tallied at "
+                        "64 B); calibrated = FETCH_SIZE*1024 + nq*4 + WRITE_SIZE*1024 (only the 16 B/lane query "
+                        "stream is wide; table-gather misses are 64-B requests counted in full)"}
     # profiles/traffic_latest.json: what bench.py reports as roofline.traffic (keyed by table mode + query set)
     import re
-    queries = sys.argv[3] if len(sys.argv) > 3 else "random"
-    nq = int(sys.argv[4]) if len(sys.argv) > 4 else 100000000
     latest = {}
     for k, t in summary.get("traffic", {}).items():
-        m = re.search(r"interp1_vec_kernel<(\d+)", k)
+        m = re.search(r"interp1_(?:vec|sweep)_kernel<(\d+)", k)
         if m:
             latest["interp1_mode%s_%s" % (m.group(1), queries)] = {
-                "nq": nq, "hbm_bytes_per_launch": t["hbm_bytes_per_launch_corrected"],
-                "hbm_bytes_per_launch_raw": t["hbm_bytes_per_launch_raw"], "kernel": k, "profile": "summary_%s.json" % tag,
-                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; (2*FETCH_SIZE + WRITE_SIZE)*1024 "
-                          "(gfx950 FETCH_SIZE halves wide reads, MI355X_MICROARCH.md section HBM); Infinity-Cache hits are counted"}
+                "nq": nq, "hbm_bytes_per_launch": t["hbm_bytes_per_launch_calibrated"],
+                "hbm_bytes_per_launch_doubled": t["hbm_bytes_per_launch_doubled"],
+                "hbm_bytes_per_launch_raw": t["hbm_bytes_per_launch_raw"],
+                "table_gather_bytes_beyond_l2": t["table_gather_bytes_beyond_l2"], "kernel": k,
+                "profile": "summary_%s.json" % tag,
+                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md section "
+                          "HBM: gfx950 FETCH_SIZE tallies a 128-B request as 64 B); calibrated on this kernel's known query "
+                          "stream: FETCH_SIZE*1024 + nq*4 + WRITE_SIZE*1024; 'doubled' = (2*FETCH_SIZE + WRITE_SIZE)*1024 is "
+                          "the upper bound; Infinity-Cache hits are counted"}
     if latest:
         json.dump(latest, open(os.path.join(out_dir, "traffic_latest.json"), "w"), indent=1)
     dst = os.path.join(out_dir, "summary_%s.json" % tag)

@@ -286,6 +286,50 @@ def test_config2_full_size_properties(mi_ctx):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("kind", ["closed_form", "jitter", "clustered"])
+def test_region_sweep_path_equals_streaming_path(mi_ctx, kind):
+    """Large unordered query sets over a table bigger than L2 take the region-sweep kernel (LDS ordering by table
+    region); its output must be bit-identical to the streaming kernel's and to the oracle, in the caller's order,
+    for every table mode, with a ragged tail, NaN / out-of-range queries, and whatever the order hint says."""
+    import armadillocudalinearinterpolation_amd as mi
+    import torch
+    n = 1_000_000
+    u = oracle.splitmix_uniform(0x5EED0002, n)
+    X = {"closed_form": np.arange(n) / (n - 1), "jitter": (np.arange(n) + 0.5 * u) / n,
+         "clustered": np.unique(np.sort(u ** 3))}[kind]
+    Y = np.sin(7 * X) + X
+    grid = mi.Grid1.from_nodes(mi_ctx, X, Y, sanitise=False)
+    assert grid.info()["mode"] == {"closed_form": 0, "jitter": 1, "clustered": 2}[kind]
+    nq = 256 * 8 * 8192 + 12345                                   # >= 8 tiles per CU, plus a ragged tail
+    g = torch.Generator(device="cuda:0").manual_seed(77)
+    xq = torch.rand(nq, dtype=torch.float64, device="cuda:0", generator=g) * 1.02 - 0.01
+    xq[:4] = torch.tensor([float("nan"), -5.0, 5.0, float(X[0])], dtype=torch.float64)
+    xq[-3:] = torch.tensor([float(X[-1]), float("nan"), 0.5], dtype=torch.float64)
+    outs = {}
+    try:
+        for name, hint in (("auto", 0), ("random", 1), ("ordered", 2)):
+            mi_ctx.set_query_order(hint)
+            outs[name] = grid.interp(xq, extrap=-3.25)
+    finally:
+        mi_ctx.set_query_order(0)
+    assert torch.equal(outs["random"].view(torch.int64), outs["ordered"].view(torch.int64))
+    assert torch.equal(outs["auto"].view(torch.int64), outs["ordered"].view(torch.int64))
+    idx = torch.cat([torch.arange(0, 4096, device="cuda:0"), torch.arange(0, nq, 997, device="cuda:0"),
+                     torch.arange(nq - 20000, nq, device="cuda:0")])
+    ref = oracle.interp1_bracket(X, Y, xq[idx].cpu().numpy(), extrap=-3.25, nthreads=8)
+    assert np.array_equal(outs["auto"][idx].cpu().numpy(), ref, equal_nan=True)
+    # ordered input through AUTO: the probe must route it to the streaming kernel and give the same values
+    xs = torch.sort(xq[4:-3]).values.contiguous()
+    mi_ctx.set_query_order(0)
+    a = grid.interp(xs)
+    mi_ctx.set_query_order(1)                                       # force the sweep kernel on ordered data
+    try:
+        b = grid.interp(xs)
+    finally:
+        mi_ctx.set_query_order(0)
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+
+
 def test_config3_full_grid_sampled(mi_ctx):
     """4096x4096 table (BASELINE.json configs[2]), 2e7 scattered queries: sampled parity + bilinear exactness."""
     import armadillocudalinearinterpolation_amd as mi
