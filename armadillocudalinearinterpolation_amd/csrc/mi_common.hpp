@@ -28,6 +28,11 @@ struct mi_ctx {
     // three ints inside the workspace: constant 0, constant 1, and the query-order probe's verdict
     static constexpr size_t kFlagOffset = 176 * 1024;
     int query_order = 0;         // MI_QUERIES_AUTO / _RANDOM / _ORDERED (mi_ctx_set_query_order)
+    // MI_QUERIES_AUTO: the probe kernel also drops its verdict into a pinned host int (never waited for); the host
+    // reads whatever is there at the next call and uses it only to PREDICT which kernel to launch -- either kernel
+    // is correct on any input.  -1 = no verdict yet (both kernels are launched, gated on the device-side flag).
+    int* probe_host = nullptr;       // host view
+    int* probe_host_dev = nullptr;   // device view of the same int
 };
 
 struct mi_timer {

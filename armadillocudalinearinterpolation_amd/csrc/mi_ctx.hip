@@ -80,6 +80,15 @@ mi_status mi_ctx_create(int device, mi_ctx** out)
         delete c;
         return mi::fail(nullptr, MI_ERR_HIP, "mi_ctx_create: workspace initialisation failed: %s", hipGetErrorString(e));
     }
+    e = hipHostMalloc(reinterpret_cast<void**>(&c->probe_host), 64, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->probe_host_dev), c->probe_host, 0);
+    if (e != hipSuccess) {
+        if (c->probe_host) (void)hipHostFree(c->probe_host);
+        (void)hipFree(c->reduce_ws);
+        delete c;
+        return mi::fail(nullptr, MI_ERR_HIP, "mi_ctx_create: probe mailbox allocation failed: %s", hipGetErrorString(e));
+    }
+    *c->probe_host = -1;
     *out = c;
     return MI_OK;
 }
@@ -90,6 +99,7 @@ mi_status mi_ctx_set_query_order(mi_ctx* ctx, int order)
     MI_REQUIRE(ctx, order == MI_QUERIES_AUTO || order == MI_QUERIES_RANDOM || order == MI_QUERIES_ORDERED,
                "mi_ctx_set_query_order: unknown value %d", order);
     ctx->query_order = order;
+    *reinterpret_cast<volatile int*>(ctx->probe_host) = -1;   // forget what earlier query sets looked like
     return MI_OK;
 }
 
@@ -100,6 +110,8 @@ mi_status mi_ctx_destroy(mi_ctx* ctx)
     for (int i = 0; i < 3; ++i)
         if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
     if (ctx->reduce_ws) hipFree(ctx->reduce_ws);
+    (void)hipStreamSynchronize(ctx->stream);   // a probe in flight may still write its mailbox
+    if (ctx->probe_host) (void)hipHostFree(ctx->probe_host);
     delete ctx;
     return MI_OK;
 }

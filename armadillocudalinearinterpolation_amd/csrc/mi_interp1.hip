@@ -182,21 +182,20 @@ __device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ]
 #ifndef MI_INTERP1_VPL
 #define MI_INTERP1_VPL 2     // 16-B vectors per lane: 1 / 2 / 4 measured 0.276 / 0.250 / 0.253 ms (sorted), random unchanged
 #endif
-template <int MODE, int FORMULA>
-__global__ __launch_bounds__(kBlock) void interp1_vec_kernel(G1Dev g, const double* __restrict__ xq,
+template <int MODE, int FORMULA, int BLOCK, int VPL>
+__global__ __launch_bounds__(BLOCK) void interp1_vec_kernel(G1Dev g, const double* __restrict__ xq,
                                                              double* __restrict__ yq, size_t nq,
                                                              double extrap, const int* __restrict__ order_flag)
 {
-    constexpr int VPL = MI_INTERP1_VPL;
     if (order_flag && *order_flag == 0) return;   // unordered queries: the region-sweep kernel does the work
     const size_t nvec = nq >> 1;
-    const size_t base = (size_t)blockIdx.x * (kBlock * VPL) + threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * (BLOCK * VPL) + threadIdx.x;
     double q[2 * VPL], r[2 * VPL];
-    bool full = base + (size_t)(VPL - 1) * kBlock < nvec;
+    bool full = base + (size_t)(VPL - 1) * BLOCK < nvec;
     if (full) {
 #pragma unroll
         for (int u = 0; u < VPL; ++u) {
-            const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2*>(xq) + base + (size_t)u * kBlock);
+            const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2*>(xq) + base + (size_t)u * BLOCK);
             q[2 * u] = v.x;
             q[2 * u + 1] = v.y;
         }
@@ -206,11 +205,11 @@ __global__ __launch_bounds__(kBlock) void interp1_vec_kernel(G1Dev g, const doub
             d2 o;
             o.x = r[2 * u];
             o.y = r[2 * u + 1];
-            __builtin_nontemporal_store(o, reinterpret_cast<d2*>(yq) + base + (size_t)u * kBlock);
+            __builtin_nontemporal_store(o, reinterpret_cast<d2*>(yq) + base + (size_t)u * BLOCK);
         }
     } else {
         for (int u = 0; u < VPL; ++u) {
-            const size_t i = base + (size_t)u * kBlock;
+            const size_t i = base + (size_t)u * BLOCK;
             if (i < nvec) {
                 const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2*>(xq) + i);
                 double q1[2] = {v.x, v.y}, r1[2];
@@ -269,11 +268,12 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
                                                                       double extrap, double bscale,
                                                                       const int* __restrict__ order_flag)
 {
-    if (*order_flag != 0) return;      // queries already locally ordered: the streaming kernel does the work
     __shared__ double sq[kSweepTile];
     __shared__ unsigned hist[kSweepBins];
     const int tid = threadIdx.x;
-    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    if (*order_flag != 0) return;            // queries already ordered locally: the streaming kernel does the work
+    bool rev = false;                        // regions are swept up, down, up, ...: L2 still holds the turn-around half
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x, rev = !rev) {
         const d2* q2 = reinterpret_cast<const d2*>(xq + t * kSweepTile);
         d2* o2 = reinterpret_cast<d2*>(yq + t * kSweepTile);
         double q[kSweepK];
@@ -320,10 +320,16 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
         for (int u = 0; u < kSweepK; u += 4) {
             double qq[4], rr[4];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) qq[w] = sq[tid + (u + w) * kSweepThreads];
+            for (int w = 0; w < 4; ++w) {
+                const int p = tid + (u + w) * kSweepThreads;
+                qq[w] = sq[rev ? kSweepTile - 1 - p : p];
+            }
             eval_batch<MODE, 4, FORMULA>(g, qq, rr, extrap);
 #pragma unroll
-            for (int w = 0; w < 4; ++w) sq[tid + (u + w) * kSweepThreads] = rr[w];
+            for (int w = 0; w < 4; ++w) {
+                const int p = tid + (u + w) * kSweepThreads;
+                sq[rev ? kSweepTile - 1 - p : p] = rr[w];
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -340,7 +346,8 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
 // Are the queries already ordered locally (sorted / clustered sets)?  1024 samples: a query and the one 4096
 // positions later fall into the same or adjacent region.  Writes 1 (ordered: streaming kernel) or 0 (sweep).
 __global__ __launch_bounds__(1024) void interp1_order_probe(const double* __restrict__ xq, size_t nq, double xmin,
-                                                            double bscale, int* __restrict__ flag)
+                                                            double bscale, int* __restrict__ flag,
+                                                            int* __restrict__ host_mailbox)
 {
     __shared__ unsigned near;
     if (threadIdx.x == 0) near = 0;
@@ -350,7 +357,11 @@ __global__ __launch_bounds__(1024) void interp1_order_probe(const double* __rest
     const int a = sweep_bin(xq[j], xmin, bscale), b = sweep_bin(xq[j + 4096], xmin, bscale);
     if (abs(a - b) <= 1) atomicAdd(&near, 1u);
     __syncthreads();
-    if (threadIdx.x == 0) *flag = (near >= 768u) ? 1 : 0;
+    if (threadIdx.x == 0) {
+        const int verdict = (near >= 768u) ? 1 : 0;
+        *flag = verdict;                                                                    // gates this call's kernels
+        __hip_atomic_store(host_mailbox, verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // predicts the next call's
+    }
 }
 
 // Scalar kernel for unaligned query/result pointers.
@@ -367,18 +378,36 @@ __global__ __launch_bounds__(kBlock) void interp1_scalar_kernel(G1Dev g, const d
     }
 }
 
-template <int MODE, int FORMULA>
-mi_status launch_vec(mi_ctx* ctx, const G1Dev& d, const double* xq, double* yq, size_t nq, double extrap,
-                     const int* order_flag)
+// Gated launches (order_flag != nullptr) exit at once when the probe saw unordered queries; what that costs is the
+// dispatch of the grid's waves (26-30 us at 1e8 queries; 1024-lane workgroups cost the same, 4x fewer waves save
+// 15-19 us but run 15 % slower on ordered input), which is why launch_mode only gates while it has no prediction.
+#ifndef MI_INTERP1_GATED_BLOCK
+#define MI_INTERP1_GATED_BLOCK 256
+#endif
+#ifndef MI_INTERP1_GATED_VPL
+#define MI_INTERP1_GATED_VPL 2
+#endif
+template <int MODE, int FORMULA, int BLOCK, int VPL>
+mi_status launch_vec_shape(mi_ctx* ctx, const G1Dev& d, const double* xq, double* yq, size_t nq, double extrap,
+                           const int* order_flag)
 {
     const size_t lanes = (nq >> 1) + (nq & 1);                 // one lane per vector (+ one for an odd tail)
-    const size_t per_block = (size_t)kBlock * MI_INTERP1_VPL;
+    const size_t per_block = (size_t)BLOCK * VPL;
     const size_t grid = (lanes + per_block - 1) / per_block;
     if (grid > 0x7fffffffull) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_interp1_f64_dev: nq=%zu too large for one launch", nq);
-    hipLaunchKernelGGL((interp1_vec_kernel<MODE, FORMULA>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, d, xq,
-                       yq, nq, extrap, order_flag);
+    hipLaunchKernelGGL((interp1_vec_kernel<MODE, FORMULA, BLOCK, VPL>), dim3((unsigned)grid), dim3(BLOCK), 0, ctx->stream,
+                       d, xq, yq, nq, extrap, order_flag);
     MI_LAUNCH_CHECK(ctx, "interp1 streaming kernel");
     return MI_OK;
+}
+
+template <int MODE, int FORMULA>
+mi_status launch_vec(mi_ctx* ctx, const G1Dev& d, const double* xq, double* yq, size_t nq, double extrap,
+                     const int* order_flag = nullptr)
+{
+    if (order_flag)
+        return launch_vec_shape<MODE, FORMULA, MI_INTERP1_GATED_BLOCK, MI_INTERP1_GATED_VPL>(ctx, d, xq, yq, nq, extrap, order_flag);
+    return launch_vec_shape<MODE, FORMULA, kBlock, MI_INTERP1_VPL>(ctx, d, xq, yq, nq, extrap, nullptr);
 }
 
 template <int MODE, int FORMULA = 0>
@@ -400,26 +429,32 @@ mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, size_t table_bytes, const dou
     const size_t ntiles = nq / kSweepTile;
     const bool sweep_ok = ctx->query_order != MI_QUERIES_ORDERED && table_bytes >= (3u << 20) &&
                           ntiles >= (size_t)cus * 4 && std::isfinite(d.xmax - d.xmin) && (d.xmax - d.xmin) > 0.0;
-    if (!sweep_ok) return launch_vec<MODE, FORMULA>(ctx, d, xq, yq, nq, extrap, nullptr);
+    if (!sweep_ok) return launch_vec<MODE, FORMULA>(ctx, d, xq, yq, nq, extrap);
 
     const double bscale = (double)kSweepBins / (d.xmax - d.xmin);
     int* flags = reinterpret_cast<int*>(static_cast<char*>(ctx->reduce_ws) + mi_ctx::kFlagOffset);   // {0, 1, probe}
-    const int* order_flag = flags;                                                                     // constant 0
-    if (ctx->query_order == MI_QUERIES_AUTO) {
-        hipLaunchKernelGGL(interp1_order_probe, dim3(1), dim3(1024), 0, ctx->stream, xq, nq, d.xmin, bscale, flags + 2);
-        MI_LAUNCH_CHECK(ctx, "interp1 order probe");
-        order_flag = flags + 2;
-    }
     const size_t head = ntiles * kSweepTile;
     const unsigned grid = (unsigned)std::min<size_t>(ntiles, (size_t)cus * MI_SWEEP_BLOCKS_PER_CU);   // persistent
+    int plan = 0;   // 0: region sweep, 1: streaming kernel, 2: both, gated on the device-side verdict
+    if (ctx->query_order == MI_QUERIES_AUTO) {
+        // What did the probe say about an earlier query set?  (Never waited for; stale or missing is fine: the
+        // verdict only selects the faster of two kernels that are both correct on any input.)
+        const int predicted = *reinterpret_cast<volatile int*>(ctx->probe_host);
+        hipLaunchKernelGGL(interp1_order_probe, dim3(1), dim3(1024), 0, ctx->stream, xq, nq, d.xmin, bscale, flags + 2,
+                           ctx->probe_host_dev);
+        MI_LAUNCH_CHECK(ctx, "interp1 order probe");
+        plan = (predicted == 0 || predicted == 1) ? predicted : 2;
+    }
+    if (plan == 1) return launch_vec<MODE, FORMULA>(ctx, d, xq, yq, nq, extrap);
+    const int* order_flag = plan == 2 ? flags + 2 : flags;          // flags[0] is a constant 0: never skip
     hipLaunchKernelGGL((interp1_sweep_kernel<MODE, FORMULA>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, d, xq, yq,
                        ntiles, extrap, bscale, order_flag);
     MI_LAUNCH_CHECK(ctx, "interp1 region-sweep kernel");
-    if (ctx->query_order == MI_QUERIES_AUTO) {      // ordered after all: the streaming kernel takes the same range
+    if (plan == 2) {                                   // ordered after all: the streaming kernel takes the same range
         mi_status st = launch_vec<MODE, FORMULA>(ctx, d, xq, yq, head, extrap, order_flag);
         if (st != MI_OK) return st;
     }
-    if (nq > head) return launch_vec<MODE, FORMULA>(ctx, d, xq + head, yq + head, nq - head, extrap, nullptr);
+    if (nq > head) return launch_vec<MODE, FORMULA>(ctx, d, xq + head, yq + head, nq - head, extrap);
     return MI_OK;
 }
 

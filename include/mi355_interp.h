@@ -74,7 +74,10 @@ int mi_abi_version(void);
 /* Hint about the order of the query vectors handed to mi_interp1_f64_dev on this context.  Unordered queries
  * over a table larger than L2 are processed by a "region sweep" kernel (workgroup-local ordering by table region
  * in LDS; results keep the caller's order), ordered/clustered ones by the plain streaming kernel.  AUTO decides on
- * the device with a 1024-sample probe (no host synchronisation); the other values skip the probe. */
+ * the device with a 1024-sample probe (no host synchronisation): the first call launches both kernels gated on the
+ * probe's flag, later calls launch only the kernel the previous probe's verdict predicts (read from a pinned host
+ * int, never waited for; both kernels are correct on any input, so a stale verdict only costs time).  The other
+ * values skip the probe; changing the value forgets the verdict.  Results never depend on any of this. */
 #define MI_QUERIES_AUTO    0
 #define MI_QUERIES_RANDOM  1
 #define MI_QUERIES_ORDERED 2

@@ -314,20 +314,32 @@ def test_region_sweep_path_equals_streaming_path(mi_ctx, kind):
         mi_ctx.set_query_order(0)
     assert torch.equal(outs["random"].view(torch.int64), outs["ordered"].view(torch.int64))
     assert torch.equal(outs["auto"].view(torch.int64), outs["ordered"].view(torch.int64))
+    # AUTO again: the first call had no verdict yet (both kernels launched, gated on the device flag); by now the
+    # probe's verdict has reached the host and predicts the kernel (region sweep only)
+    mi_ctx.synchronize()
+    again = grid.interp(xq, extrap=-3.25)
+    assert torch.equal(again.view(torch.int64), outs["ordered"].view(torch.int64))
     idx = torch.cat([torch.arange(0, 4096, device="cuda:0"), torch.arange(0, nq, 997, device="cuda:0"),
                      torch.arange(nq - 20000, nq, device="cuda:0")])
     ref = oracle.interp1_bracket(X, Y, xq[idx].cpu().numpy(), extrap=-3.25, nthreads=8)
     assert np.array_equal(outs["auto"][idx].cpu().numpy(), ref, equal_nan=True)
-    # ordered input through AUTO: the probe must route it to the streaming kernel and give the same values
+    # ordered input through AUTO: the first call is mispredicted from the random set above (region sweep on ordered
+    # data), the second follows the new verdict (streaming kernel); both must equal the hinted paths
     xs = torch.sort(xq[4:-3]).values.contiguous()
-    mi_ctx.set_query_order(0)
-    a = grid.interp(xs)
-    mi_ctx.set_query_order(1)                                       # force the sweep kernel on ordered data
+    a1 = grid.interp(xs)
+    mi_ctx.synchronize()
+    a2 = grid.interp(xs)
     try:
+        mi_ctx.set_query_order(1)                                   # force the region sort on ordered data
         b = grid.interp(xs)
+        mi_ctx.set_query_order(2)                                   # streaming kernel
+        c = grid.interp(xs)
+        mi_ctx.set_query_order(0)                                   # hint change forgets the verdict: gated launch
+        a3 = grid.interp(xs)
     finally:
         mi_ctx.set_query_order(0)
-    assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+    for other in (a2, a3, b, c):
+        assert torch.equal(a1.view(torch.int64), other.view(torch.int64))
 
 
 def test_config3_full_grid_sampled(mi_ctx):
