@@ -423,11 +423,12 @@ mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, size_t table_bytes, const dou
         MI_LAUNCH_CHECK(ctx, "interp1 scalar kernel");
         return MI_OK;
     }
-    // Region sweep only pays when the table cannot live in one XCD's 4 MiB L2 and there are enough tiles to keep
-    // every CU busy for several sweeps; ordered query sets are detected on the device (or declared by the caller).
+    // Region sweep only pays when the table cannot live in one XCD's 4 MiB L2 (measured window, random queries,
+    // profiles/r01_sweep_vs_stream_by_table_size.log: 0.91-0.99x below 5 MB, 1.06x at 5.6 MB, 1.39x at 8 MB, 1.7x at
+    // 16-32 MB, still 1.05x at 512 MB) and there are enough tiles to keep every CU busy for several sweeps; ordered query sets are detected on the device (or declared by the caller).
     const unsigned cus = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256);
     const size_t ntiles = nq / kSweepTile;
-    const bool sweep_ok = ctx->query_order != MI_QUERIES_ORDERED && table_bytes >= (3u << 20) &&
+    const bool sweep_ok = ctx->query_order != MI_QUERIES_ORDERED && table_bytes >= (5u << 20) &&
                           ntiles >= (size_t)cus * 4 && std::isfinite(d.xmax - d.xmin) && (d.xmax - d.xmin) > 0.0;
     if (!sweep_ok) return launch_vec<MODE, FORMULA>(ctx, d, xq, yq, nq, extrap);
 

@@ -202,7 +202,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(ginfo["mode"], args.queries, nq),
-            "kernel": ("interp1_sweep_kernel<%d,...> (region sweep)" if (args.queries == "random" and ginfo["table_bytes"] >= (3 << 20)
+            "kernel": ("interp1_sweep_kernel<%d,...> (region sweep)" if (args.queries == "random" and ginfo["table_bytes"] >= (5 << 20)
                                                                        and nq // 16384 >= 4 * info["compute_units"])
                        else "interp1_vec_kernel<%d,...> (streaming)") % ginfo["mode"],
             "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
