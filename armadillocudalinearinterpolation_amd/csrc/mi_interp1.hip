@@ -175,6 +175,51 @@ __device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ]
     }
 }
 
+#ifndef MI_SWEEP_BINS
+#define MI_SWEEP_BINS 256
+#endif
+constexpr int kSweepBins = MI_SWEEP_BINS;
+
+__device__ __forceinline__ int sweep_bin(double q, double xmin, double bscale)
+{
+    const int b = (int)((q - xmin) * bscale);             // NaN -> 0, out of range clamps: any bin is correct
+    return min(max(b, 0), kSweepBins - 1);
+}
+
+// Are the queries already ordered locally (sorted / clustered sets)?  1024 samples: a query and the one 4096
+// positions later fall into the same or adjacent region; >= 75 % => ordered (streaming kernel), else unordered
+// (region sweep).  One wave does it (16 samples per lane, no LDS): either as its own kernel, ahead of kernels gated
+// on the verdict, or inside the interpolation kernel when the verdict is only wanted for the next call.
+struct ProbeArgs {
+    const double* xq;    // the whole query vector of the call
+    size_t nq;           // >= 4098
+    double xmin, bscale;
+    int* flag;           // device-side verdict (may be null)
+    int* host_mailbox;   // pinned host int, device view (null: no probe)
+};
+
+__device__ __forceinline__ void order_probe_wave(const ProbeArgs& p)
+{
+    const int lane = threadIdx.x & 63;
+    const double step = (double)(p.nq - 4097) / 1024.0;
+    unsigned near = 0;
+#pragma unroll 8
+    for (int k = 0; k < 16; ++k) {
+        const size_t j = (size_t)(((double)(k * 64 + lane) + 0.5) * step);
+        const int a = sweep_bin(p.xq[j], p.xmin, p.bscale), b = sweep_bin(p.xq[j + 4096], p.xmin, p.bscale);
+        near += (abs(a - b) <= 1) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) near += __shfl_xor(near, off, 64);
+    if (lane == 0) {
+        const int verdict = (near >= 768u) ? 1 : 0;
+        if (p.flag) *p.flag = verdict;                                                            // gates this call's kernels
+        __hip_atomic_store(p.host_mailbox, verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // predicts the next call's
+    }
+}
+
+__global__ __launch_bounds__(64) void interp1_order_probe(ProbeArgs p) { order_probe_wave(p); }
+
 // Vector kernel: a fixed VPL = 2 16-B vectors (four queries) per lane and one workgroup per 8 KiB of
 // queries, no grid-stride loop.  Measured on MI355X (profiles/r01_exp_stream_shapes.log): this shape streams 8 B in +
 // 8 B out per element at 6.5 TB/s, a grid capped at 2048 workgroups with a grid-stride loop at 5.0 TB/s.
@@ -185,9 +230,11 @@ __device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ]
 template <int MODE, int FORMULA, int BLOCK, int VPL>
 __global__ __launch_bounds__(BLOCK) void interp1_vec_kernel(G1Dev g, const double* __restrict__ xq,
                                                              double* __restrict__ yq, size_t nq,
-                                                             double extrap, const int* __restrict__ order_flag)
+                                                             double extrap, const int* __restrict__ order_flag,
+                                                             ProbeArgs probe)
 {
     if (order_flag && *order_flag == 0) return;   // unordered queries: the region-sweep kernel does the work
+    if (probe.host_mailbox && blockIdx.x == 0 && threadIdx.x < 64) order_probe_wave(probe);   // for the next call
     const size_t nvec = nq >> 1;
     const size_t base = (size_t)blockIdx.x * (BLOCK * VPL) + threadIdx.x;
     double q[2 * VPL], r[2 * VPL];
@@ -228,17 +275,20 @@ __global__ __launch_bounds__(BLOCK) void interp1_vec_kernel(G1Dev g, const doubl
 }
 
 // ---- region sweep: random queries over a table that does not fit L2 ------------------------------------
-// A uniformly random gather costs one 64-B L2 transaction per query, and with an 8 MB table ~40 % of them miss
-// the 4 MiB L2 of the XCD (DESIGN.md "Random queries").  The misses go away if, at any moment, the whole chip
-// works on the same table region.  Persistent workgroups (all start together, all do the same work per tile)
-// each take a tile of 16384 queries (128 KiB of LDS, one workgroup of 512 lanes per CU), order it by table region
-// with an in-LDS counting sort (256 regions), and gather + blend in that order: lane j of step u holds sorted
-// position j + 512u, so every wave of every CU is in about the same region at about the same time and L2 only
-// has to hold that region.  Shapes measured in the product kernel (1e8 queries, 1e6 nodes): 256x32x2/CU 0.872 ms,
-// 1024x16 0.823, 512x32 0.787 (64 regions), 0.770 (256 regions), 0.797 (1024 regions).  Results overwrite the
-// sorted LDS slot; each lane reads its own results back through the sorted positions it remembered and stores
-// them coalesced, so the output order is untouched.  Arithmetic = eval_batch, identical to the streaming kernel.
-// Prototype measurements: profiles/r01_exp_region_sweep_*.log (1.07 -> 0.76 ms with a lighter evaluation).
+// A uniformly random gather is one L2 request per query, and with an 8 MB table ~40 % of them miss the 4 MiB L2
+// of the XCD (DESIGN.md "Random queries").  The misses go away if, at any moment, the whole chip works on the same
+// table region.  Persistent workgroups (all start together, all do the same work per tile, so they stay in step
+// without synchronising) each take a tile of 16384 queries (128 KiB of LDS, one workgroup of 512 lanes per CU),
+// order it by table region with an in-LDS counting sort (256 regions), and gather + blend in that order: lane j of
+// round u holds sorted position j + 512u, so every wave of every CU is in about the same region at about the same
+// time and L2 only has to hold that region.  Successive tiles sweep the regions up, down, up, ...: the half of the
+// table touched last is still in L2 when the next tile starts there (gather misses 12.0 M -> 7.8 M per launch).
+// Results overwrite the sorted LDS slot; each lane reads its own results back through the sorted positions it
+// remembered and stores them coalesced, so the output order is untouched.  Arithmetic = eval_batch, identical to
+// the streaming kernel.  Shapes measured in this kernel (1e8 queries, 1e6 nodes, before the up/down order):
+// 256x32x2/CU 0.872 ms, 1024x16 0.823, 512x32 0.787 (64 regions), 0.770 (256), 0.797 (1024); with the up/down
+// order 0.69 ms.  Phase times, the L2 request-rate ceiling (2.7e11 gathers/s chip-wide) and the overlap schemes
+// that did not pay: DESIGN.md section 4, profiles/r01_exp_region_sweep_phases.log, r01_exp_gather_rate.log.
 #ifndef MI_SWEEP_THREADS
 #define MI_SWEEP_THREADS 512
 #endif
@@ -251,27 +301,21 @@ __global__ __launch_bounds__(BLOCK) void interp1_vec_kernel(G1Dev g, const doubl
 constexpr int kSweepThreads = MI_SWEEP_THREADS;
 constexpr int kSweepK = MI_SWEEP_K;                       // queries per lane per tile
 constexpr int kSweepTile = kSweepThreads * kSweepK;       // queries per tile (8 B of LDS each)
-#ifndef MI_SWEEP_BINS
-#define MI_SWEEP_BINS 256
-#endif
-constexpr int kSweepBins = MI_SWEEP_BINS;
-
-__device__ __forceinline__ int sweep_bin(double q, double xmin, double bscale)
-{
-    const int b = (int)((q - xmin) * bscale);             // NaN -> 0, out of range clamps: any bin is correct
-    return min(max(b, 0), kSweepBins - 1);
-}
-
 template <int MODE, int FORMULA>
 __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, const double* __restrict__ xq,
                                                                       double* __restrict__ yq, size_t ntiles,
                                                                       double extrap, double bscale,
-                                                                      const int* __restrict__ order_flag)
+                                                                      const int* __restrict__ order_flag,
+                                                                      size_t tail, ProbeArgs probe)
 {
     __shared__ double sq[kSweepTile];
     __shared__ unsigned hist[kSweepBins];
     const int tid = threadIdx.x;
     if (*order_flag != 0) return;            // queries already ordered locally: the streaming kernel does the work
+    // The last workgroup has the fewest tiles: it also probes the query order for the next call (one wave, while
+    // the others wait for their first tile) and evaluates the ragged tail after its tiles.
+    const bool last_wg = blockIdx.x == gridDim.x - 1;
+    if (probe.host_mailbox && last_wg && tid < 64) order_probe_wave(probe);
     bool rev = false;                        // regions are swept up, down, up, ...: L2 still holds the turn-around half
     for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x, rev = !rev) {
         const d2* q2 = reinterpret_cast<const d2*>(xq + t * kSweepTile);
@@ -341,26 +385,26 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
         }
         __syncthreads();   // the next tile's scatter reuses sq
     }
-}
-
-// Are the queries already ordered locally (sorted / clustered sets)?  1024 samples: a query and the one 4096
-// positions later fall into the same or adjacent region.  Writes 1 (ordered: streaming kernel) or 0 (sweep).
-__global__ __launch_bounds__(1024) void interp1_order_probe(const double* __restrict__ xq, size_t nq, double xmin,
-                                                            double bscale, int* __restrict__ flag,
-                                                            int* __restrict__ host_mailbox)
-{
-    __shared__ unsigned near;
-    if (threadIdx.x == 0) near = 0;
-    __syncthreads();
-    const size_t span = nq - 4097;
-    const size_t j = (size_t)(((double)threadIdx.x + 0.5) * (double)span / 1024.0);
-    const int a = sweep_bin(xq[j], xmin, bscale), b = sweep_bin(xq[j + 4096], xmin, bscale);
-    if (abs(a - b) <= 1) atomicAdd(&near, 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int verdict = (near >= 768u) ? 1 : 0;
-        *flag = verdict;                                                                    // gates this call's kernels
-        __hip_atomic_store(host_mailbox, verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // predicts the next call's
+    if (tail && last_wg) {
+        const double* tq = xq + ntiles * kSweepTile;
+        double* to = yq + ntiles * kSweepTile;
+        double q[kSweepK];                   // tail < one tile: all loads in flight at once, one latency
+#pragma unroll
+        for (int u = 0; u < kSweepK; ++u) {
+            const size_t i = (size_t)tid + (size_t)u * kSweepThreads;
+            q[u] = i < tail ? tq[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kSweepK; u += 4) {
+            const double qq[4] = {q[u], q[u + 1], q[u + 2], q[u + 3]};
+            double rr[4];
+            eval_batch<MODE, 4, FORMULA>(g, qq, rr, extrap);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const size_t i = (size_t)tid + (size_t)(u + w) * kSweepThreads;
+                if (i < tail) to[i] = rr[w];
+            }
+        }
     }
 }
 
@@ -389,25 +433,25 @@ __global__ __launch_bounds__(kBlock) void interp1_scalar_kernel(G1Dev g, const d
 #endif
 template <int MODE, int FORMULA, int BLOCK, int VPL>
 mi_status launch_vec_shape(mi_ctx* ctx, const G1Dev& d, const double* xq, double* yq, size_t nq, double extrap,
-                           const int* order_flag)
+                           const int* order_flag, const ProbeArgs& probe)
 {
     const size_t lanes = (nq >> 1) + (nq & 1);                 // one lane per vector (+ one for an odd tail)
     const size_t per_block = (size_t)BLOCK * VPL;
     const size_t grid = (lanes + per_block - 1) / per_block;
     if (grid > 0x7fffffffull) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_interp1_f64_dev: nq=%zu too large for one launch", nq);
     hipLaunchKernelGGL((interp1_vec_kernel<MODE, FORMULA, BLOCK, VPL>), dim3((unsigned)grid), dim3(BLOCK), 0, ctx->stream,
-                       d, xq, yq, nq, extrap, order_flag);
+                       d, xq, yq, nq, extrap, order_flag, probe);
     MI_LAUNCH_CHECK(ctx, "interp1 streaming kernel");
     return MI_OK;
 }
 
 template <int MODE, int FORMULA>
 mi_status launch_vec(mi_ctx* ctx, const G1Dev& d, const double* xq, double* yq, size_t nq, double extrap,
-                     const int* order_flag = nullptr)
+                     const int* order_flag = nullptr, const ProbeArgs& probe = ProbeArgs{})
 {
     if (order_flag)
-        return launch_vec_shape<MODE, FORMULA, MI_INTERP1_GATED_BLOCK, MI_INTERP1_GATED_VPL>(ctx, d, xq, yq, nq, extrap, order_flag);
-    return launch_vec_shape<MODE, FORMULA, kBlock, MI_INTERP1_VPL>(ctx, d, xq, yq, nq, extrap, nullptr);
+        return launch_vec_shape<MODE, FORMULA, MI_INTERP1_GATED_BLOCK, MI_INTERP1_GATED_VPL>(ctx, d, xq, yq, nq, extrap, order_flag, probe);
+    return launch_vec_shape<MODE, FORMULA, kBlock, MI_INTERP1_VPL>(ctx, d, xq, yq, nq, extrap, nullptr, probe);
 }
 
 template <int MODE, int FORMULA = 0>
@@ -436,26 +480,32 @@ mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, size_t table_bytes, const dou
     int* flags = reinterpret_cast<int*>(static_cast<char*>(ctx->reduce_ws) + mi_ctx::kFlagOffset);   // {0, 1, probe}
     const size_t head = ntiles * kSweepTile;
     const unsigned grid = (unsigned)std::min<size_t>(ntiles, (size_t)cus * MI_SWEEP_BLOCKS_PER_CU);   // persistent
-    int plan = 0;   // 0: region sweep, 1: streaming kernel, 2: both, gated on the device-side verdict
+    // plan 0: region sweep, 1: streaming kernel, 2: separate probe, then both kernels gated on its device-side flag
+    int plan = 0;
+    ProbeArgs probe{};   // host_mailbox == nullptr: no probe
     if (ctx->query_order == MI_QUERIES_AUTO) {
         // What did the probe say about an earlier query set?  (Never waited for; stale or missing is fine: the
         // verdict only selects the faster of two kernels that are both correct on any input.)
         const int predicted = *reinterpret_cast<volatile int*>(ctx->probe_host);
-        hipLaunchKernelGGL(interp1_order_probe, dim3(1), dim3(1024), 0, ctx->stream, xq, nq, d.xmin, bscale, flags + 2,
-                           ctx->probe_host_dev);
-        MI_LAUNCH_CHECK(ctx, "interp1 order probe");
         plan = (predicted == 0 || predicted == 1) ? predicted : 2;
+        probe = ProbeArgs{xq, nq, d.xmin, bscale, plan == 2 ? flags + 2 : nullptr, ctx->probe_host_dev};
     }
-    if (plan == 1) return launch_vec<MODE, FORMULA>(ctx, d, xq, yq, nq, extrap);
-    const int* order_flag = plan == 2 ? flags + 2 : flags;          // flags[0] is a constant 0: never skip
-    hipLaunchKernelGGL((interp1_sweep_kernel<MODE, FORMULA>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, d, xq, yq,
-                       ntiles, extrap, bscale, order_flag);
-    MI_LAUNCH_CHECK(ctx, "interp1 region-sweep kernel");
-    if (plan == 2) {                                   // ordered after all: the streaming kernel takes the same range
-        mi_status st = launch_vec<MODE, FORMULA>(ctx, d, xq, yq, head, extrap, order_flag);
+    if (plan == 1) return launch_vec<MODE, FORMULA>(ctx, d, xq, yq, nq, extrap, nullptr, probe);   // probes inline
+    if (plan == 2) {
+        hipLaunchKernelGGL(interp1_order_probe, dim3(1), dim3(64), 0, ctx->stream, probe);
+        MI_LAUNCH_CHECK(ctx, "interp1 order probe");
+        hipLaunchKernelGGL((interp1_sweep_kernel<MODE, FORMULA>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, d, xq,
+                           yq, ntiles, extrap, bscale, flags + 2, (size_t)0, ProbeArgs{});
+        MI_LAUNCH_CHECK(ctx, "interp1 region-sweep kernel");
+        mi_status st = launch_vec<MODE, FORMULA>(ctx, d, xq, yq, head, extrap, flags + 2);   // ordered after all
         if (st != MI_OK) return st;
+        if (nq > head) return launch_vec<MODE, FORMULA>(ctx, d, xq + head, yq + head, nq - head, extrap);
+        return MI_OK;
     }
-    if (nq > head) return launch_vec<MODE, FORMULA>(ctx, d, xq + head, yq + head, nq - head, extrap);
+    // one launch: sort-and-gather tiles, the ragged tail, and the probe for the next call (flags[0] is a constant 0)
+    hipLaunchKernelGGL((interp1_sweep_kernel<MODE, FORMULA>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, d, xq, yq,
+                       ntiles, extrap, bscale, flags, nq - head, probe);
+    MI_LAUNCH_CHECK(ctx, "interp1 region-sweep kernel");
     return MI_OK;
 }
 

@@ -340,6 +340,35 @@ def test_region_sweep_path_equals_streaming_path(mi_ctx, kind):
         mi_ctx.set_query_order(0)
     for other in (a2, a3, b, c):
         assert torch.equal(a1.view(torch.int64), other.view(torch.int64))
+    # hipGraph: capture the AUTO call (probe + whatever launch plan is in force), replay it on query sets of the
+    # other kind in the same buffers -- the plan is frozen in the graph, the results must not care
+    buf = xs.clone()
+    out = torch.zeros_like(buf)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    try:
+        with torch.cuda.stream(side):
+            mi_ctx.use_torch_stream()
+            grid.interp(buf, out=out)                                   # warm-up outside capture
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                mi_ctx.use_torch_stream()
+                grid.interp(buf, out=out)
+        torch.cuda.current_stream().wait_stream(side)
+    finally:
+        mi_ctx.use_torch_stream()
+    for src, want in ((xq[4:-3], outs["ordered"][4:-3]), (xs, a1)):
+        buf.copy_(src)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        # same queries, default extrap (NaN) here vs -3.25 above: compare where the reference value is in range
+        if want is a1:
+            assert torch.equal(out.view(torch.int64), want.view(torch.int64))
+        else:
+            inside = (src >= float(X[0])) & (src <= float(X[-1]))
+            assert torch.equal(out[inside].view(torch.int64), want[inside].view(torch.int64))
+            assert bool(torch.isnan(out[~inside]).all())
 
 
 def test_config3_full_grid_sampled(mi_ctx):
