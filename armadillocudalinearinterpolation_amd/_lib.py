@@ -36,6 +36,7 @@ class EdmParams(C.Structure):
         ("mean_quirk", C.c_int),
         ("max_events", C.c_uint32),
         ("real_offset", C.c_uint32),
+        ("dedup_identical", C.c_uint32),
     ]
 
 

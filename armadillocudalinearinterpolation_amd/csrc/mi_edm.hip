@@ -290,6 +290,29 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
     }
 }
 
+// dedup_identical: replicate the events of the one evolved realisation into every [spike][realisation] row
+__global__ __launch_bounds__(256) void replicate_events_kernel(unsigned S, unsigned R, const float* __restrict__ one_t0,
+                                                               const unsigned short* __restrict__ one_i0,
+                                                               const float* __restrict__ one_t1,
+                                                               const unsigned short* __restrict__ one_i1,
+                                                               const unsigned* __restrict__ one_accept,
+                                                               float* __restrict__ t0, unsigned short* __restrict__ i0,
+                                                               float* __restrict__ t1, unsigned short* __restrict__ i1,
+                                                               unsigned* __restrict__ accept)
+{
+    const unsigned acc = one_accept[0];
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (size_t)gridDim.x * blockDim.x) {
+        for (unsigned m = 0; m < S; ++m) {
+            const size_t k = (size_t)m * R + r;
+            t0[k] = one_t0[m];
+            i0[k] = one_i0[m];
+            t1[k] = one_t1[m];
+            i1[k] = one_i1[m];
+        }
+        accept[r] = acc;
+    }
+}
+
 template <int MATH>
 __global__ void math_probe_kernel(int op, const float* a, const float* b, float* out, size_t n)
 {
@@ -316,6 +339,7 @@ struct mi_edm {
     float *d_t0 = nullptr, *d_t1 = nullptr, *d_restricted = nullptr;
     uint16_t *d_i0 = nullptr, *d_i1 = nullptr;
     uint32_t* d_accept = nullptr;
+    char* d_one = nullptr;         // dedup_identical: events of the one evolved realisation (kOneBytes)
     char* d_result = nullptr;      // mean f32[8] | count u32 (+pad) | sums f64[8]
     char* h_result = nullptr;      // pinned mirror
     size_t alloc_real = 0;
@@ -329,6 +353,8 @@ struct mi_edm {
 namespace {
 
 constexpr size_t kResultBytes = 8 * 4 + 8 + 8 * 8;
+// t0 f32[8] | t1 f32[8] | i0 u16[8] | i1 u16[8] | accept u32
+constexpr size_t kOneT0 = 0, kOneT1 = 32, kOneI0 = 64, kOneI1 = 80, kOneAccept = 96, kOneBytes = 128;
 
 mi_status validate(const mi_ctx* ctx, const mi_edm_params* p)
 {
@@ -440,14 +466,35 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd)
     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
     const unsigned cap = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256) * per_cu * 4u;
     if (blocks > cap) blocks = cap;
+    // dedup_identical: without heterogeneity the realisations are R copies of one computation
+    const bool dedup = e->p.dedup_identical != 0 && !hetero && R > 1;
+    edm::Model M = e->M;
+    float *t0 = e->d_t0, *t1 = e->d_t1;
+    uint16_t *i0 = e->d_i0, *i1 = e->d_i1;
+    uint32_t* accept = e->d_accept;
+    if (dedup) {
+        M.R = 1;
+        blocks = 1;
+        t0 = (float*)(e->d_one + kOneT0);
+        t1 = (float*)(e->d_one + kOneT1);
+        i0 = (uint16_t*)(e->d_one + kOneI0);
+        i1 = (uint16_t*)(e->d_one + kOneI1);
+        accept = (uint32_t*)(e->d_one + kOneAccept);
+    }
 #define MI_EVOLVE(H, NS)                                                                                          \
-    hipLaunchKernelGGL((evolve_kernel<MATH, H, NS>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, e->M, sd, \
-                       e->d_v, e->d_s, e->d_w, e->d_t0, e->d_i0, e->d_t1, e->d_i1, e->d_accept)
+    hipLaunchKernelGGL((evolve_kernel<MATH, H, NS>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, M, sd, \
+                       e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept)
     const bool three = e->p.n_spikes <= 3;
     if (hetero) { if (three) MI_EVOLVE(true, 3); else MI_EVOLVE(true, kMaxSpikes); }
     else { if (three) MI_EVOLVE(false, 3); else MI_EVOLVE(false, kMaxSpikes); }
 #undef MI_EVOLVE
     MI_LAUNCH_CHECK(ctx, "evolve kernel");
+    if (dedup) {
+        const unsigned grid = mi::stream_grid(ctx, R, 256);
+        hipLaunchKernelGGL(replicate_events_kernel, dim3(grid), dim3(256), 0, ctx->stream, e->p.n_spikes, R, t0, i0, t1, i1,
+                           accept, e->d_t0, e->d_i0, e->d_t1, e->d_i1, e->d_accept);
+        MI_LAUNCH_CHECK(ctx, "replicate-events kernel");
+    }
     return MI_OK;
 }
 
@@ -501,6 +548,7 @@ void mi_edm_default_params(mi_edm_params* p)
     p->mean_quirk = 0;
     p->max_events = 1u << 20;
     p->real_offset = 0;
+    p->dedup_identical = 0;
 }
 
 mi_status mi_edm_create(mi_ctx* ctx, const mi_edm_params* p, mi_edm** out)
@@ -520,6 +568,7 @@ mi_status mi_edm_create(mi_ctx* ctx, const mi_edm_params* p, mi_edm** out)
     if (err == hipSuccess) err = hipMalloc(&e->d_s, kMaxGrid * sizeof(float));
     if (err == hipSuccess) err = hipMalloc(&e->d_w, kMaxGrid * sizeof(float));
     if (err == hipSuccess) err = hipMalloc(&e->d_result, kResultBytes);
+    if (err == hipSuccess) err = hipMalloc(&e->d_one, kOneBytes);
     if (err == hipSuccess) err = hipHostMalloc(&e->h_result, kResultBytes);
     for (int i = 0; i < 4 && err == hipSuccess; ++i) err = hipEventCreate(&e->ev[i]);
     if (err != hipSuccess) {
@@ -537,7 +586,7 @@ mi_status mi_edm_destroy(mi_edm* e)
     if (!e) return MI_OK;
     (void)hipSetDevice(e->ctx->device);
     free_real_buffers(e);
-    void* bufs[] = {e->d_v, e->d_s, e->d_w, e->d_result};
+    void* bufs[] = {e->d_v, e->d_s, e->d_w, e->d_result, e->d_one};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_result) (void)hipHostFree(e->h_result);

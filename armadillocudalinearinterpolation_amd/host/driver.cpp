@@ -1,6 +1,6 @@
 // The reference's fixed problem (Driver.cu:11-126) on the MI355X path: beta = 13.0589, Z0 = (0.3310, 0.6914,
 // 1.3557), Newton tolerance 1e-4, max 10 iterations, forward-difference epsilon 1e-2, damping 1, 512 grid points.
-//   driver [--real R] [--threads N] [--fast] [--debug DIR] [--json FILE] [--quiet] [--stability]
+//   driver [--real R] [--threads N] [--fast] [--dedup] [--debug DIR] [--json FILE] [--quiet] [--stability]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -16,12 +16,13 @@ int main(int argc, char* argv[])
 {
     unsigned int noReal = 1000;        // Driver.cu:19
     int noThreads = 512;               // Driver.cu:69
-    bool fast = false, quiet = false, stability = false;
+    bool fast = false, quiet = false, stability = false, dedup = false;
     const char *debug_dir = nullptr, *json = nullptr;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--real") && i + 1 < argc) noReal = std::strtoul(argv[++i], nullptr, 10);
         else if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) noThreads = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--fast")) fast = true;
+        else if (!std::strcmp(argv[i], "--dedup")) dedup = true;   // sigma == 0: evolve one realisation, replicate it
         else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
         else if (!std::strcmp(argv[i], "--stability")) stability = true;
         else if (!std::strcmp(argv[i], "--debug") && i + 1 < argc) debug_dir = argv[++i];
@@ -34,6 +35,7 @@ int main(int argc, char* argv[])
     EventDrivenMap event(&parameters, noReal);
     event.SetQuiet(quiet);
     if (fast) event.SetMathMode(MI_EDM_MATH_FAST);
+    if (dedup) event.SetDedupIdentical(true);
 
     arma::vec guess(3);                                          // Driver.cu:23-24 (float literals)
     guess(0) = 0.3310f; guess(1) = 0.6914f; guess(2) = 1.3557f;

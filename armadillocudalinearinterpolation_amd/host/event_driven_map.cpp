@@ -151,6 +151,12 @@ void EventDrivenMap::SetRealisationOffset(unsigned int offset)
     Push();
 }
 
+void EventDrivenMap::SetDedupIdentical(bool on)
+{
+    p_.dedup_identical = on ? 1u : 0u;
+    Push();
+}
+
 void EventDrivenMap::LastTimingsMs(float ms[4]) const { must(mi_edm_last_timings(edm_, ms), ctx_, "mi_edm_last_timings"); }
 
 // The reference's only verification mechanism: one "%f" per line per stage (EventDrivenMap.cu:406-503, :911-917).

@@ -35,6 +35,7 @@ class EventDrivenMap : public AbstractNonlinearProblem {
     // extensions (not in the reference)
     void SetMathMode(int mode);                      // MI_EDM_MATH_EXACT / MI_EDM_MATH_FAST
     void SetRealisationOffset(unsigned int offset);  // this rank's first global realisation (multi-GPU shards)
+    void SetDedupIdentical(bool on);                 // sigma == 0: evolve one realisation, replicate (bit-identical)
     void SetDebugDirectory(const std::string& dir) { debug_dir_ = dir; }
     void SetQuiet(bool q) { quiet_ = q; }
     // un-normalised accepted sums (S values) + accepted count of the last ComputeF, for an all-reduce

@@ -266,6 +266,17 @@ def main():
                 "realisations_per_s": 125_000 / (tmg["total_ms"] * 1e-3),
                 "note": "compute-bound in Evolve (fp32 exp/log/div), not a bandwidth roofline case"}
             edm.close()
+        # the same call with the opt-in shortcut for sigma = 0 (config 4 has sigma = 0: its realisations are R copies of
+        # one computation); reported beside the full evolution above, never instead of it
+        edm = mi.EventDrivenMap(ctx, [13.0589], 125_000, n_grid=1024, dedup_identical=1)
+        edm.ComputeF(zd)
+        edm.ComputeF(zd)
+        tmg = edm.last_timings()
+        extra["compute_f_125k_real_1024pts_exact_dedup_identical"] = {
+            "ms": tmg["total_ms"], "evolve_ms": tmg["evolve_ms"], "restrict_mean_ms": tmg["restrict_mean_ms"],
+            "note": "opt-in mi_edm_params.dedup_identical: one realisation evolved, events replicated to all rows; "
+                    "outputs bit-identical to the full evolution (tests/test_edm_gpu.py); only valid for sigma = 0"}
+        edm.close()
     if world > 1 and not args.no_extra and args.dist_backend == "nccl":
         full = torch.empty(world * nq, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(full, yq)

@@ -212,6 +212,13 @@ typedef struct mi_edm_params {
     uint32_t real_offset;              /* global index of this shard's first
                                           realisation (multi-GPU sharding; only
                                           enters the per-neuron beta draw)       */
+    uint32_t dedup_identical;          /* opt-in, default 0: with beta_stddev == 0
+                                          every realisation is the same computation
+                                          (the draw is the only per-realisation
+                                          input, EventDrivenMap.cu:179,196); evolve
+                                          one and replicate its events to all n_real
+                                          rows.  Outputs are bit-identical to the
+                                          full evolution; ignored when stddev != 0 */
 } mi_edm_params;
 #define MI_EDM_MATH_EXACT 0   /* software exp/log, bit-identical to oracle/edm_oracle.c */
 #define MI_EDM_MATH_FAST  1   /* v_exp_f32 / v_log_f32 hardware transcendentals          */

@@ -164,6 +164,22 @@ def test_many_realisations_are_identical_when_sigma_is_zero(mi_ctx):
     assert t["evolve_ms"] > 0 and t["total_ms"] >= t["evolve_ms"]
 
 
+def test_dedup_identical_is_bit_identical_to_full_evolution(mi_ctx):
+    """Opt-in shortcut for sigma = 0 (all realisations are one computation): evolve one, replicate its events.
+    Every stage tap, the count, the sums and f must equal the full evolution; with sigma > 0 the flag is ignored."""
+    for n_grid, n_real in ((1024, 4099), (512, 20000)):
+        _, f_full, p_full, d_full = _run(mi_ctx, n_grid=n_grid, n_real=n_real)
+        edm, f_dd, p_dd, d_dd = _run(mi_ctx, n_grid=n_grid, n_real=n_real, dedup_identical=1)
+        assert np.array_equal(f_full, f_dd) and np.array_equal(p_full, p_dd)
+        for k in ("t0", "i0", "t1", "i1", "accept", "restricted"):
+            assert np.array_equal(d_full[k], d_dd[k]), k
+        assert edm.last_timings()["evolve_ms"] > 0
+    _, f_full, p_full, d_full = _run(mi_ctx, n_grid=512, n_real=3000, beta_stddev=0.3)
+    _, f_dd, p_dd, d_dd = _run(mi_ctx, n_grid=512, n_real=3000, beta_stddev=0.3, dedup_identical=1)
+    assert np.array_equal(f_full, f_dd) and np.array_equal(p_full, p_dd)
+    assert np.array_equal(d_full["t0"], d_dd["t0"]) and not np.all(d_dd["t0"].reshape(3, 3000) == d_dd["t0"].reshape(3, 3000)[:, :1])
+
+
 def test_python_newton_on_gpu_matches_oracle_newton(mi_ctx):
     """The replicated Newton loop used for multi-GPU runs (newton.py), here on one GPU with 1024 grid points."""
     import armadillocudalinearinterpolation_amd as mi
