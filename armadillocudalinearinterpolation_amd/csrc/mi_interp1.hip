@@ -48,6 +48,8 @@ struct G1Dev {
     double rden;         // RN(1/den), formula 3
     int formula;         // mode 0: closed form of the abscissae
     int pin_last;        // mode 0: node n-1 is xmax exactly (not the closed form)
+    double gorg;         // mode 1, centred guess: G(x) = (int)((x - gorg) * scale) equals i at EVERY node i (build_explicit)
+    int centred;         // mode 1: the centred guess holds -> the bracket is G(q) - 1 or G(q), no walk
 };
 
 struct mi_grid1 {
@@ -96,7 +98,10 @@ __device__ __forceinline__ double unode(const G1Dev& g, int i)
 // NQ independent queries per lane: all guesses first, then all gathers (so the
 // loads of the NQ queries are in flight together), then the rare fix-up walks
 // and the blend.
-template <int MODE, int NQ, int FORMULA = 0>
+// WIN (mode 3 only): fetch node G-1 together with G and G+1 (ordered queries: the lanes share lines and the extra
+// gather is nearly free, while a dependent one would stall the stream); without it node G-1 is fetched only by the
+// lanes that need it (unordered queries: every gather is an L2 request).
+template <int MODE, int NQ, int FORMULA = 0, bool WIN = false>
 __device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ], double (&out)[NQ],
                                            double extrap)
 {
@@ -127,6 +132,32 @@ __device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ]
         for (int k = 0; k < NQ; ++k) yp[k] = *reinterpret_cast<const ypair*>(g.y + l[k]);
 #pragma unroll
         for (int k = 0; k < NQ; ++k) out[k] = blend(xl[k], yp[k].a, xr[k], yp[k].b, qs[k]);
+    } else if constexpr (MODE == 3) {
+        // Mode 1 with a centred guess: G is monotone and G(X_i) == i at every node (verified at build time with
+        // this very expression), so X_l <= q < X_{l+1} gives G(q) in {l, l+1}: the bracket is G-1 or G.  Three
+        // independent gathers, a select, no dependent load and no loop.
+        d2 nm[NQ], n0[NQ], n1[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int i = (int)((qs[k] - g.gorg) * g.scale);
+            l[k] = min(max(i, 0), g.n - 1);
+        }
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            if constexpr (WIN) nm[k] = g.nodes[max(l[k] - 1, 0)];
+            n0[k] = g.nodes[l[k]];
+            n1[k] = g.nodes[l[k] + 1];        // index n is the padding node
+        }
+        if constexpr (!WIN) {   // fetch node G-1 only where it is needed (one dependent gather, no loop)
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) nm[k] = (qs[k] < n0[k].x) ? g.nodes[max(l[k] - 1, 0)] : n0[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const bool down = qs[k] < n0[k].x;   // then l = G-1 >= 0 (G = 0 has X_0 <= q)
+            const d2 a = down ? nm[k] : n0[k], b = down ? n0[k] : n1[k];
+            out[k] = blend(a.x, a.y, b.x, b.y, qs[k]);
+        }
     } else {
         d2 n0[NQ], n1[NQ];
         if constexpr (MODE == 1) {
@@ -246,7 +277,7 @@ __global__ __launch_bounds__(BLOCK) void interp1_vec_kernel(G1Dev g, const doubl
             q[2 * u] = v.x;
             q[2 * u + 1] = v.y;
         }
-        eval_batch<MODE, 2 * VPL, FORMULA>(g, q, r, extrap);
+        eval_batch<MODE, 2 * VPL, FORMULA, true>(g, q, r, extrap);
 #pragma unroll
         for (int u = 0; u < VPL; ++u) {
             d2 o;
@@ -625,6 +656,46 @@ mi_status build_explicit(mi_ctx* ctx, const std::vector<double>& xs, const std::
     if (finite_scale && (e_hi - e_lo + 1) <= kMaxWalk) {
         g->mode = 1;
         d.scale = scale1;
+        // Centred guess: shift the origin so that every node's scaled abscissa sits inside its own unit cell,
+        // t_i = (X_i - gorg) * scale in [i + m, i + 1 - m].  Holds whenever the grid deviates from a straight line by
+        // less than one cell (jittered / mildly stretched grids).  Accepted only if the device expression gives
+        // exactly i at every node; then eval_batch<3> needs no walk (see there).
+        // Two candidate slopes: through the end nodes, and the least-squares line (end nodes of a jittered grid are
+        // themselves jittered, which tilts the first one by up to a cell over the length of the table).
+        double mi_ = 0.0, mx = 0.0;
+        for (size_t i = 0; i < n; ++i) { mi_ += (double)i; mx += xs[i] - d.xmin; }
+        mi_ /= (double)n;
+        mx /= (double)n;
+        double sxy = 0.0, sxx = 0.0;
+        for (size_t i = 0; i < n; ++i) {
+            const double di = (double)i - mi_;
+            sxy += di * ((xs[i] - d.xmin) - mx);
+            sxx += di * di;
+        }
+        const double cand[2] = {scale1, (sxy > 0.0) ? sxx / sxy : 0.0};
+        for (int c = 0; c < 2 && !d.centred; ++c) {
+            const double sc = cand[c];
+            if (!(sc > 0.0) || !std::isfinite(sc) || n >= 0x7fffff00u) continue;
+            double dlo = INFINITY, dhi = -INFINITY;
+            for (size_t i = 0; i < n; ++i) {
+                const double di = (xs[i] - d.xmin) * sc - (double)i;
+                dlo = std::min(dlo, di);
+                dhi = std::max(dhi, di);
+            }
+            const double m = 0.5 * (1.0 - (dhi - dlo));
+            if (!(m > 1e-6)) continue;
+            const double gorg = d.xmin + (dlo - m) / sc;
+            bool ok = std::isfinite(gorg);
+            for (size_t i = 0; i < n && ok; ++i) {
+                const double t = (xs[i] - gorg) * sc;
+                ok = t >= 0.0 && t < 2147483000.0 && (size_t)(int)t == i;
+            }
+            if (ok) {
+                d.gorg = gorg;
+                d.scale = sc;
+                d.centred = 1;
+            }
+        }
     } else {
         g->mode = 2;
         size_t nb = n;
@@ -776,7 +847,7 @@ mi_status mi_grid1_info(const mi_grid1* g, size_t* n_nodes, int* mode, size_t* t
 {
     MI_REQUIRE(nullptr, g != nullptr, "mi_grid1_info: grid is NULL");
     if (n_nodes) *n_nodes = g->n;
-    if (mode) *mode = g->mode;
+    if (mode) *mode = (g->mode == 1 && g->d.centred) ? 3 : g->mode;
     if (table_bytes) *table_bytes = g->table_bytes;
     return MI_OK;
 }
@@ -794,7 +865,9 @@ mi_status mi_interp1_f64_dev(mi_ctx* ctx, const mi_grid1* g, const double* xq, d
             if (g->d.formula == 2) return launch_mode<0, 2>(ctx, g->d, g->table_bytes, xq, yq, nq, extrap);
             if (g->d.formula == 3) return launch_mode<0, 3>(ctx, g->d, g->table_bytes, xq, yq, nq, extrap);
             return launch_mode<0, 0>(ctx, g->d, g->table_bytes, xq, yq, nq, extrap);
-        case 1: return launch_mode<1>(ctx, g->d, g->table_bytes, xq, yq, nq, extrap);
+        case 1:
+            if (g->d.centred) return launch_mode<3>(ctx, g->d, g->table_bytes, xq, yq, nq, extrap);
+            return launch_mode<1>(ctx, g->d, g->table_bytes, xq, yq, nq, extrap);
         default: return launch_mode<2>(ctx, g->d, g->table_bytes, xq, yq, nq, extrap);
     }
 }

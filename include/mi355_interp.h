@@ -117,8 +117,10 @@ mi_status mi_grid1_destroy(mi_grid1* g);
 /* number of nodes after sanitising; table mode chosen at build time
  * (0 = Y only, abscissae from a closed form -- declared by
  *      mi_grid1_create_uniform or detected on an explicit grid,
- *  1 = explicit {x,y} nodes + analytic guess,
- *  2 = explicit {x,y} nodes + bucket index) */
+ *  1 = explicit {x,y} nodes + analytic guess and a bounded walk,
+ *  2 = explicit {x,y} nodes + bucket index,
+ *  3 = explicit {x,y} nodes + centred analytic guess: the grid stays within
+ *      one cell of a straight line, the bracket is one comparison away) */
 mi_status mi_grid1_info(const mi_grid1* g, size_t* n_nodes, int* mode, size_t* table_bytes);
 
 /* ---- 1-D interpolation: the hot path -----------------------------------

@@ -48,7 +48,7 @@ def test_config1_golden(mi_ctx, golden_dir, tag):
     assert _eq(mi.interp1(mi_ctx, X, Y, xi), out)
 
 
-@pytest.mark.parametrize("name,mode", [("interp1_nonuniform.npz", 1), ("interp1_clustered.npz", 2)])
+@pytest.mark.parametrize("name,mode", [("interp1_nonuniform.npz", 3), ("interp1_clustered.npz", 2)])
 def test_general_grid_golden(mi_ctx, golden_dir, name, mode):
     import armadillocudalinearinterpolation_amd as mi
     g = _load(golden_dir, name)
@@ -111,7 +111,7 @@ def test_ragged_sizes_all_modes(mi_ctx, nq):
     u = oracle.splitmix_uniform(1234, ng)
     grids = {
         "uniformX": (np.arange(ng) / (ng - 1), 0),            # closed form detected -> implicit table
-        "jitterX": ((np.arange(ng) + 0.5 * u) / ng, 1),
+        "jitterX": ((np.arange(ng) + 0.5 * u) / ng, 3),
         "clustered": (np.unique(np.sort(u ** 5)), 2),
     }
     q = oracle.splitmix_uniform(4321 + nq, nq) * 1.1 - 0.05
@@ -160,9 +160,37 @@ def test_closed_form_detection_is_bit_exact(mi_ctx):
     X = np.arange(n) / (n - 1)
     X[777] = np.nextafter(X[777], 1.0)
     g = mi.Grid1.from_nodes(mi_ctx, X, np.cos(X))
-    assert g.info()["mode"] == 1
+    assert g.info()["mode"] == 3
     q = oracle.splitmix_uniform(6, 50000)
     assert _eq(g.interp(_t(q)).cpu().numpy(), oracle.interp1_bracket(X, np.cos(X), q))
+
+
+def test_explicit_grids_with_analytic_guess_are_bit_exact_around_every_node(mi_ctx):
+    """Explicit {x,y} tables with an analytic guess come in two forms: mode 3, the centred guess (grid within one cell
+    of a straight line: bracket = G-1 or G, no walk) and mode 1, the generic guess + bounded walk.  Both must equal the oracle on every node,
+    one ulp either side of every node, cell midpoints and random queries -- the places where an off-by-one bracket
+    would show."""
+    import armadillocudalinearinterpolation_amd as mi
+    n = 30011
+    i = np.arange(n, dtype=np.float64)
+    u = oracle.splitmix_uniform(99, n)
+    grids = {
+        "jitter_half_cell": ((i + 0.5 * u) / n, 3),                      # BASELINE's non-uniform variant
+        "jitter_0.9_cell": ((i + 0.9 * u) / n, 3),                       # still within one cell of a line
+        "one_perturbed_node": (np.where(i == 777, np.nextafter(i / (n - 1), 1.0), i / (n - 1)), 3),
+        "stretched": ((i / (n - 1)) ** 1.00002 * 3.0 - 1.0, 3),          # slow drift of about a quarter cell
+        "jitter_1.5_cells": (np.unique(np.sort((i + 1.5 * u) / n)), 1),  # more than a cell: generic guess + walk
+        "offset_scale": (1e6 + 1e-3 * (i + 0.3 * np.sin(i)), 3),         # large offset, small spacing
+    }
+    for name, (X, want_mode) in grids.items():
+        X = np.ascontiguousarray(X)
+        Y = np.sin(5 * (X - X[0]) / (X[-1] - X[0])) + 0.25 * X
+        g = mi.Grid1.from_nodes(mi_ctx, X, Y, sanitise=False)
+        assert g.info()["mode"] == want_mode, name
+        q = np.concatenate([X, np.nextafter(X, np.inf), np.nextafter(X, -np.inf), 0.5 * (X[1:] + X[:-1]),
+                            oracle.splitmix_uniform(7, 200000) * (X[-1] - X[0]) * 1.01 + X[0] - 0.005 * (X[-1] - X[0]),
+                            [np.nan, -np.inf, np.inf, X[0], X[-1]]])
+        assert _eq(g.interp(_t(q)).cpu().numpy(), oracle.interp1_bracket(X, Y, q)), name
 
 
 def test_queries_on_nodes_and_cell_midpoints(mi_ctx):
@@ -299,7 +327,7 @@ def test_region_sweep_path_equals_streaming_path(mi_ctx, kind):
          "clustered": np.unique(np.sort(u ** 3))}[kind]
     Y = np.sin(7 * X) + X
     grid = mi.Grid1.from_nodes(mi_ctx, X, Y, sanitise=False)
-    assert grid.info()["mode"] == {"closed_form": 0, "jitter": 1, "clustered": 2}[kind]
+    assert grid.info()["mode"] == {"closed_form": 0, "jitter": 3, "clustered": 2}[kind]
     nq = 256 * 8 * 8192 + 12345                                   # >= 8 tiles per CU, plus a ragged tail
     g = torch.Generator(device="cuda:0").manual_seed(77)
     xq = torch.rand(nq, dtype=torch.float64, device="cuda:0", generator=g) * 1.02 - 0.01
