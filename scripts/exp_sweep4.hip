@@ -337,6 +337,125 @@ float run2(const char* name, const double* y, int n, const double* xq, double* y
     printf("\n");
     return ts[ts.size() / 2];
 }
+// k3: two wave groups of 512 threads, EACH with its own LDS tile (2 x 64 KiB), locked half a tile period apart by the
+// workgroup barriers: while one group gathers (L2-bound), the other stores its previous tile, loads, histograms,
+// prefixes and scatters its next one (HBM- and LDS-bound).  Group 0 sweeps the regions upwards, group 1 downwards.
+template <int K, int NB, int TIMED>
+__global__ __launch_bounds__(1024) void k3(const double* __restrict__ y, int n, double dx, double inv_dx, const double* __restrict__ xq, double* __restrict__ yq, size_t nq, unsigned long long* __restrict__ ph) {
+    constexpr int GT = 512, T = GT * K, G = K / 4;      // 4 gather rounds of G queries
+    __shared__ double sq2[2][T];
+    __shared__ unsigned hist2[2][NB];
+    const int grp = threadIdx.x >> 9, tid = threadIdx.x & (GT - 1);
+    double* sq = sq2[grp];
+    unsigned* hist = hist2[grp];
+    const size_t ntiles = nq / T;
+    const double bscale = (double)NB;
+    // tiles of this workgroup: pairs (2p, 2p+1) for p = blockIdx.x, blockIdx.x + gridDim.x, ...
+    const size_t npairs = (ntiles + 1) / 2;
+    const int J = (blockIdx.x < npairs) ? (int)((npairs - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;   // tiles per group
+    unsigned long long acc[NPH] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last = TIMED ? wall_clock64() : 0;
+    d2 qv[K / 2];
+    unsigned pk[K / 2];
+    const bool rev = grp != 0;
+    auto tile_of = [&](int j) -> size_t { return ((size_t)blockIdx.x + (size_t)j * gridDim.x) * 2 + grp; };
+    for (int h = 0; h <= 2 * J + 1; ++h) {
+        const int hh = h - grp;
+        const bool prep = hh >= 0 && (hh & 1) == 0;
+        const int j = prep ? hh / 2 : (hh - 1) / 2;
+        const bool have = hh >= (prep ? 0 : 1) && j < J && tile_of(j) < ntiles;          // tile j exists for this group
+        const bool have_prev = prep && j >= 1 && j - 1 < J && tile_of(j - 1) < ntiles;
+        if (prep) {
+            // interval 0: store the previous tile's results, issue the loads of the next tile
+            if (have_prev) {
+                d2* o2 = (d2*)(yq + tile_of(j - 1) * T);
+#pragma unroll
+                for (int u = 0; u < K / 2; ++u) { d2 v; v.x = sq[pk[u] & 0xffffu]; v.y = sq[pk[u] >> 16]; __builtin_nontemporal_store(v, o2 + tid + u * GT); }
+            }
+            if (have) {
+                const d2* q2 = (const d2*)(xq + tile_of(j) * T);
+#pragma unroll
+                for (int u = 0; u < K / 2; ++u) qv[u] = __builtin_nontemporal_load(q2 + tid + u * GT);
+                for (int b = tid; b < NB; b += GT) hist[b] = 0;
+            }
+        } else if (have) {
+#pragma unroll
+            for (int w = 0; w < G; ++w) { const int p = tid + (0 * G + w) * GT; const int pp = rev ? T - 1 - p : p; const double qq = sq[pp]; int i = (int)(qq * inv_dx); i = min(max(i, 0), n - 2); const ypair yp = *(const ypair*)(y + i); sq[pp] = blend(i * dx, yp.a, (i + 1) * dx, yp.b, qq); }
+        }
+        __syncthreads();
+        STAMP(0)
+        if (prep) {
+            if (have) {
+#pragma unroll
+                for (int u = 0; u < K / 2; ++u) {
+                    int b0 = (int)(qv[u].x * bscale); b0 = min(max(b0, 0), NB - 1);
+                    int b1 = (int)(qv[u].y * bscale); b1 = min(max(b1, 0), NB - 1);
+                    const unsigned r0 = atomicAdd(&hist[b0], 1u), r1 = atomicAdd(&hist[b1], 1u);
+                    pk[u] = r0 | (r1 << 16);
+                }
+            }
+        } else if (have) {
+#pragma unroll
+            for (int w = 0; w < G; ++w) { const int p = tid + (1 * G + w) * GT; const int pp = rev ? T - 1 - p : p; const double qq = sq[pp]; int i = (int)(qq * inv_dx); i = min(max(i, 0), n - 2); const ypair yp = *(const ypair*)(y + i); sq[pp] = blend(i * dx, yp.a, (i + 1) * dx, yp.b, qq); }
+        }
+        __syncthreads();
+        STAMP(1)
+        if (prep) {
+            if (have && tid < 64) {
+                unsigned run = 0;
+                for (int base = 0; base < NB; base += 64) {
+                    const int b = base + tid; unsigned v = (b < NB) ? hist[b] : 0, incl = v;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) { unsigned o = __shfl_up(incl, off, 64); if (tid >= off) incl += o; }
+                    if (b < NB) hist[b] = run + incl - v;
+                    run += __shfl(incl, 63, 64);
+                }
+            }
+        } else if (have) {
+#pragma unroll
+            for (int w = 0; w < G; ++w) { const int p = tid + (2 * G + w) * GT; const int pp = rev ? T - 1 - p : p; const double qq = sq[pp]; int i = (int)(qq * inv_dx); i = min(max(i, 0), n - 2); const ypair yp = *(const ypair*)(y + i); sq[pp] = blend(i * dx, yp.a, (i + 1) * dx, yp.b, qq); }
+        }
+        __syncthreads();
+        STAMP(2)
+        if (prep) {
+            if (have) {
+#pragma unroll
+                for (int u = 0; u < K / 2; ++u) {
+                    int b0 = (int)(qv[u].x * bscale); b0 = min(max(b0, 0), NB - 1);
+                    int b1 = (int)(qv[u].y * bscale); b1 = min(max(b1, 0), NB - 1);
+                    const unsigned p0 = hist[b0] + (pk[u] & 0xffffu), p1 = hist[b1] + (pk[u] >> 16);
+                    sq[p0] = qv[u].x; sq[p1] = qv[u].y;
+                    pk[u] = p0 | (p1 << 16);
+                }
+            }
+        } else if (have) {
+#pragma unroll
+            for (int w = 0; w < G; ++w) { const int p = tid + (3 * G + w) * GT; const int pp = rev ? T - 1 - p : p; const double qq = sq[pp]; int i = (int)(qq * inv_dx); i = min(max(i, 0), n - 2); const ypair yp = *(const ypair*)(y + i); sq[pp] = blend(i * dx, yp.a, (i + 1) * dx, yp.b, qq); }
+        }
+        __syncthreads();
+        STAMP(3)
+    }
+    if (TIMED && threadIdx.x == 0) for (int i = 0; i < NPH; ++i) ph[blockIdx.x * NPH + i] = acc[i];
+}
+template <int K, int NB, int TIMED>
+float run3(const char* name, const double* y, int n, const double* xq, double* yq, size_t nq, int blocks, unsigned long long* ph) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); double dx = 1.0 / (n - 1);
+    hipLaunchKernelGGL((k3<K, NB, TIMED>), dim3(blocks), dim3(1024), 0, 0, y, n, dx, 1.0 / dx, xq, yq, nq, ph); CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int r = 0; r < 5; ++r) { CK(hipEventRecord(a)); hipLaunchKernelGGL((k3<K, NB, TIMED>), dim3(blocks), dim3(1024), 0, 0, y, n, dx, 1.0 / dx, xq, yq, nq, ph); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms); }
+    std::sort(ts.begin(), ts.end());
+    printf("%-34s K %2d bins %3d blocks %4d : %.4f ms", name, K, NB, blocks, ts[ts.size() / 2]);
+    if (TIMED) {
+        std::vector<unsigned long long> h((size_t)blocks * NPH); CK(hipMemcpy(h.data(), ph, h.size() * 8, hipMemcpyDeviceToHost));
+        const double halfsteps = (double)(nq / ((size_t)512 * K)) / blocks; double tot = 0;     // = tiles per workgroup = half-steps (2 groups)
+        printf("  | us per half-step interval:");
+        const char* nm[4] = {"store+load|G1", "hist|G2", "prefix|G3", "scatter|G4"};
+        for (int i = 0; i < 4; ++i) { double s = 0; for (int bl = 0; bl < blocks; ++bl) s += (double)h[(size_t)bl * NPH + i]; s = s / blocks / halfsteps * 0.01; tot += s; printf(" %s %.2f", nm[i], s); }
+        printf(" sum %.2f", tot);
+    }
+    printf("\n");
+    return ts[ts.size() / 2];
+}
 int main(int argc, char** argv) {
     const int n = 1000000; const size_t nq = 100000000 / 65536 * 65536;
     std::vector<double> hy(n + 1); for (int i = 0; i <= n; ++i) hy[i] = sin(6.28 * i / n);
@@ -349,12 +468,12 @@ int main(int argc, char** argv) {
     run<512, 32, 256, 1, 0, 0, 4, 0>("1 wg/CU 512x32 ascending (reference output)", y, n, xq, yq, nq, 256, ph);
     double* yr; CK(hipMalloc(&yr, nq * 8)); CK(hipMemcpy(yr, yq, nq * 8, hipMemcpyDeviceToDevice));
     run<512, 32, 256, 1, 0, 0, 4, 1>("1 wg/CU 512x32 boustrophedon", y, n, xq, yq, nq, 256, ph);
-    runp<512, 32, 256, 1, 4, 0>("kp baseline timed", y, n, xq, yq, nq, 256, ph);
-    runp<512, 32, 256, 0, 4, 0>("kp baseline", y, n, xq, yq, nq, 256, ph);
-    runp<512, 32, 256, 1, 4, 0, 700>("kp XCD halves offset 7 us timed", y, n, xq, yq, nq, 256, ph);
-    runp<512, 32, 256, 0, 4, 0, 700>("kp XCD halves offset 7 us", y, n, xq, yq, nq, 256, ph);
-    runp<512, 32, 256, 1, 4, 0, 1400>("kp XCD halves offset 14 us timed", y, n, xq, yq, nq, 256, ph);
-    runp<512, 32, 256, 0, 4, 0, 1400>("kp XCD halves offset 14 us", y, n, xq, yq, nq, 256, ph);
-    runp<512, 32, 256, 0, 4, 0, 2000>("kp XCD halves offset 20 us", y, n, xq, yq, nq, 256, ph);
+    runp<512, 32, 256, 0, 4, 0>("kp baseline (1 tile of 16K per CU)", y, n, xq, yq, nq, 256, ph);
+    CK(hipMemset(yq, 0, nq * 8));
+    run3<16, 256, 0>("k3 two groups, two LDS tiles of 8K", y, n, xq, yq, nq, 256, ph);
+    { std::vector<double> a(nq), b(nq); CK(hipMemcpy(a.data(), yq, nq * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), yr, nq * 8, hipMemcpyDeviceToHost)); size_t bad = 0; for (size_t i2 = 0; i2 < nq; ++i2) bad += a[i2] != b[i2]; printf("mismatches of k3 vs reference: %zu of %zu\n", bad, nq); }
+    run3<16, 256, 1>("k3 timed", y, n, xq, yq, nq, 256, ph);
+    run3<16, 128, 0>("k3 128 regions", y, n, xq, yq, nq, 256, ph);
+    run3<16, 512, 0>("k3 512 regions", y, n, xq, yq, nq, 256, ph);
     return 0;
 }
