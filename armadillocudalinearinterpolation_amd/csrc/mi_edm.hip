@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <new>
+#include <cstdlib>
 #include <vector>
 
 #include "mi_common.hpp"
@@ -290,6 +291,170 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
     }
 }
 
+// ---- EvolveKernel, latency form: one WORKGROUP of W waves per realisation ---------------------------------
+// With few realisations (the reference's Driver.cu runs 1000, dedup_identical runs 1) the wave-per-realisation kernel
+// leaves most SIMDs with at most one wave and every event pays the full latency of a 16-neuron-per-lane state pass
+// (5.3 us per event at N = 1024).  Here the neurons of one realisation are spread over W waves (slice q = k*W + wave
+// holds neurons q*64 .. q*64+63); every wave keeps its own copy of the (wave-uniform) event bookkeeping, and the
+// only exchange per event is the lexicographic (time, index) minimum: each wave's DPP minimum goes through a
+// double-buffered LDS slot and one barrier.  Arithmetic per neuron and the arg-min rule are those of evolve_kernel,
+// so the results are bit-identical (tests/test_edm_gpu.py).
+template <int MATH, bool HETERO, int NS, int W>
+__global__ __launch_bounds__(64 * W) void evolve_wg_kernel(edm::Model M, SpikeSeeds sd, const float* __restrict__ v0,
+                                                           const float* __restrict__ s0, const float* __restrict__ w,
+                                                           float* __restrict__ g_t0, unsigned short* __restrict__ g_i0,
+                                                           float* __restrict__ g_t1, unsigned short* __restrict__ g_i1,
+                                                           unsigned* __restrict__ g_accept)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr unsigned kBlockT = 64u * W;
+    const unsigned npl = (M.N + kBlockT - 1u) / kBlockT;      // slices per wave
+    const unsigned slots = npl * kBlockT;
+    float* w_lds = lds;
+    for (unsigned i = threadIdx.x; i < (unsigned)kMaxGrid; i += kBlockT) w_lds[i] = (i < M.N) ? w[i] : 0.0f;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float* V = lds + kMaxGrid;
+    float* S = V + slots;
+    float* B = S + slots;                                      // only touched when HETERO
+    unsigned* red = reinterpret_cast<unsigned*>(S + slots + (HETERO ? slots : 0u));   // [2][W][2]: time bits, index
+    const unsigned full = (1u << M.S) - 1u;
+    const float two_T = 2.0f * M.T;
+    __syncthreads();
+
+    for (unsigned r = blockIdx.x; r < M.R; r += gridDim.x) {
+        for (unsigned k = 0; k < npl; ++k) {
+            const unsigned i = (k * W + wave) * 64u + lane;
+            const bool act = i < M.N;
+            V[i] = act ? v0[i] : 0.0f;
+            S[i] = act ? s0[i] : 0.0f;
+            if constexpr (HETERO) B[i] = edm::beta_of<MATH>(M.beta_mean, M.beta_sigma, M.seed, M.N, (uint64_t)r + M.real_offset, act ? i : 0u);
+        }
+        float lt[NS], ct[NS];
+        unsigned li[NS], ci[NS];
+#pragma unroll
+        for (int m = 0; m < NS; ++m) {
+            lt[m] = 0.0f;
+            ct[m] = 0.0f;
+            ci[m] = 0u;
+            li[m] = (m < (int)M.S) ? (unsigned)sd.ind[m] : 0u;
+        }
+        unsigned crossed = 0;
+        float now = 0.0f;
+        float base_t = INFINITY;
+        unsigned base_i = 0;
+        unsigned pend = 0;
+        for (unsigned k = 0; k < npl; ++k) {
+            const unsigned i = (k * W + wave) * 64u + lane;
+            if (i < M.N) {
+                const float bk = HETERO ? B[i] : M.beta_mean;
+                if (edm::will_fire<MATH>(M, V[i], S[i], bk)) pend |= (1u << k);
+                else if (base_t == INFINITY) { base_t = edm::kNever; base_i = i; }
+            }
+        }
+        unsigned events = 0;
+        while (crossed < full && now < two_T && events < M.max_events) {
+            ++events;
+            float best = base_t;
+            unsigned idx = base_i;
+            while (__any(pend != 0u)) {
+                if (pend != 0u) {
+                    const unsigned k = (unsigned)__builtin_ctz(pend);
+                    pend &= pend - 1u;
+                    const unsigned i = (k * W + wave) * 64u + lane;
+                    const float bk = HETERO ? B[i] : M.beta_mean;
+                    const float tau = edm::newton_time<MATH>(M, V[i], S[i], bk);
+                    if (tau < best || (tau == best && i < idx)) { best = tau; idx = i; }
+                }
+            }
+            wave_argmin(best, idx);
+            // workgroup-wide lexicographic minimum through LDS (double-buffered by event parity: one barrier per event)
+            unsigned* slot = red + (events & 1u) * (2u * W);
+            if (lane == 0) {
+                slot[2u * wave] = __float_as_uint(best);
+                slot[2u * wave + 1u] = idx;
+            }
+            __syncthreads();
+            {
+                unsigned tb = slot[0], ib = slot[1];
+#pragma unroll
+                for (int q = 1; q < W; ++q) {
+                    const unsigned t2 = slot[2 * q], i2 = slot[2 * q + 1];
+                    if (t2 < tb || (t2 == tb && i2 < ib)) { tb = t2; ib = i2; }
+                }
+                best = __uint_as_float(tb);
+                idx = ib;
+            }
+            const float dt = best;
+            const float e1 = edm::expf_<MATH>(-dt);
+            float e2u = 0.0f, e3u = 0.0f;
+            if constexpr (!HETERO) {
+                e2u = edm::expf_<MATH>((1.0f - M.beta_mean) * dt);
+                e3u = edm::expf_<MATH>(-M.beta_mean * dt);
+            }
+            base_t = INFINITY;
+            base_i = 0;
+            for (unsigned k = 0; k < npl; ++k) {
+                const unsigned sl = k * W + wave;
+                const unsigned i = sl * 64u + lane;
+                const float bk = HETERO ? B[i] : M.beta_mean;
+                const float e2 = HETERO ? edm::expf_<MATH>((1.0f - bk) * dt) : e2u;
+                const float e3 = HETERO ? edm::expf_<MATH>(-bk * dt) : e3u;
+                const float so = S[i];
+                float vv = V[i] * e1;
+                vv = vv + (M.I * (1.0f - e1) + edm::div_<MATH>(so * e1, 1.0f - bk) * (e2 - 1.0f));
+                if (sl == (idx >> 6)) vv = vv * ((i != idx) ? 1.0f : 0.0f);
+                float sn = so * e3;
+                const unsigned dist = (unsigned)abs((int)i - (int)idx);
+                sn = sn + bk * w_lds[dist & (kMaxGrid - 1)];
+                V[i] = vv;
+                S[i] = sn;
+                if (i < M.N) {
+                    if (edm::will_fire<MATH>(M, vv, sn, bk)) pend |= (1u << k);
+                    else if (base_t == INFINITY) { base_t = edm::kNever; base_i = i; }
+                }
+            }
+            now = now + dt;
+            unsigned mi = 0;
+#pragma unroll
+            for (int m = 1; m < NS; ++m) {
+                if (m < (int)M.S) {
+                    unsigned lmi = li[0];
+#pragma unroll
+                    for (int j = 1; j < NS; ++j) lmi = (mi == (unsigned)j) ? li[j] : lmi;
+                    const int dm = abs((int)idx - (int)li[m]);
+                    const int d0 = abs((int)idx - (int)lmi);
+                    mi += (dm < d0) ? 1u : 0u;
+                }
+            }
+            if (!(crossed & (1u << mi))) {
+                const bool after = now > M.T;
+#pragma unroll
+                for (int m = 0; m < NS; ++m) {
+                    if (mi == (unsigned)m) {
+                        if (after) { ct[m] = now; ci[m] = idx; }
+                        else { lt[m] = now; li[m] = idx; }
+                    }
+                }
+                if (after) crossed += (1u << mi);
+            }
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int m = 0; m < NS; ++m) {
+                if (lane == (unsigned)m && m < (int)M.S) {
+                    const size_t k = (size_t)m * M.R + r;
+                    g_t0[k] = lt[m];
+                    g_i0[k] = (unsigned short)li[m];
+                    g_t1[k] = ct[m];
+                    g_i1[k] = (unsigned short)ci[m];
+                }
+            }
+            if (lane == 0) g_accept[r] = (crossed == full) ? 1u : 0u;
+        }
+        __syncthreads();   // the next realisation re-initialises V/S and reuses the reduction slots
+    }
+}
+
 // dedup_identical: replicate the events of the one evolved realisation into every [spike][realisation] row
 __global__ __launch_bounds__(256) void replicate_events_kernel(unsigned S, unsigned R, const float* __restrict__ one_t0,
                                                                const unsigned short* __restrict__ one_i0,
@@ -353,6 +518,11 @@ struct mi_edm {
 namespace {
 
 constexpr size_t kResultBytes = 8 * 4 + 8 + 8 * 8;
+// evolve kernel choice by realisation count (launch_evolve): below kWgNarrow four waves per realisation (latency
+// form), else one wave per realisation (throughput form).  scripts/gpu_edm_wpr.py, N = 1024: R <= 256 4.6 -> 2.6 ms,
+// R = 1000 equal, R >= 2000 the throughput form wins (2x at 16 K); 16 waves per realisation were slower than 4
+// everywhere (3.1 ms): the event's critical path is the Newton solve and the exp chain, not the state pass.
+constexpr unsigned kWgNarrow = 600;
 // t0 f32[8] | t1 f32[8] | i0 u16[8] | i1 u16[8] | accept u32
 constexpr size_t kOneT0 = 0, kOneT1 = 32, kOneI0 = 64, kOneI1 = 80, kOneAccept = 96, kOneBytes = 128;
 
@@ -481,13 +651,35 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd)
         i1 = (uint16_t*)(e->d_one + kOneI1);
         accept = (uint32_t*)(e->d_one + kOneAccept);
     }
+    // Few realisations: spread each one over a workgroup of 4 waves (evolve_wg_kernel, bit-identical results).
+    // MI_EDM_WAVES_PER_REALISATION = 1 | 4 overrides the choice (test / tuning hook).
+    const unsigned Reff = M.R;
+    int wpr = (Reff < kWgNarrow) ? 4 : 1;
+    if (const char* env = getenv("MI_EDM_WAVES_PER_REALISATION")) {
+        const int v = atoi(env);
+        if (v == 1 || v == 4) wpr = v;
+    }
+    const bool three = e->p.n_spikes <= 3;
+    if (wpr == 1) {
 #define MI_EVOLVE(H, NS)                                                                                          \
     hipLaunchKernelGGL((evolve_kernel<MATH, H, NS>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, M, sd, \
                        e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept)
-    const bool three = e->p.n_spikes <= 3;
-    if (hetero) { if (three) MI_EVOLVE(true, 3); else MI_EVOLVE(true, kMaxSpikes); }
-    else { if (three) MI_EVOLVE(false, 3); else MI_EVOLVE(false, kMaxSpikes); }
+        if (hetero) { if (three) MI_EVOLVE(true, 3); else MI_EVOLVE(true, kMaxSpikes); }
+        else { if (three) MI_EVOLVE(false, 3); else MI_EVOLVE(false, kMaxSpikes); }
 #undef MI_EVOLVE
+    } else {
+        const unsigned bt = 64u * (unsigned)wpr;
+        const unsigned wslots = ((N + bt - 1) / bt) * bt;
+        const size_t wlds = ((size_t)kMaxGrid + (size_t)(hetero ? 3 : 2) * wslots) * sizeof(float) + (size_t)4 * wpr * sizeof(unsigned);
+        const unsigned wper_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / wlds));
+        const unsigned wblocks = std::min<unsigned>(Reff, (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256) * wper_cu);
+#define MI_EVOLVE_WG(H, NS, WV)                                                                                   \
+    hipLaunchKernelGGL((evolve_wg_kernel<MATH, H, NS, WV>), dim3(wblocks), dim3(64 * WV), wlds, ctx->stream, M, sd,  \
+                       e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept)
+        if (hetero) { if (three) MI_EVOLVE_WG(true, 3, 4); else MI_EVOLVE_WG(true, kMaxSpikes, 4); }
+        else { if (three) MI_EVOLVE_WG(false, 3, 4); else MI_EVOLVE_WG(false, kMaxSpikes, 4); }
+#undef MI_EVOLVE_WG
+    }
     MI_LAUNCH_CHECK(ctx, "evolve kernel");
     if (dedup) {
         const unsigned grid = mi::stream_grid(ctx, R, 256);
