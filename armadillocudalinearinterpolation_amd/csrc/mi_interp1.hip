@@ -101,10 +101,14 @@ __device__ __forceinline__ double unode(const G1Dev& g, int i)
 // WIN (mode 3 only): fetch node G-1 together with G and G+1 (ordered queries: the lanes share lines and the extra
 // gather is nearly free, while a dependent one would stall the stream); without it node G-1 is fetched only by the
 // lanes that need it (unordered queries: every gather is an L2 request).
-template <int MODE, int NQ, int FORMULA = 0, bool WIN = false>
-__device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ], double (&out)[NQ],
-                                           double extrap)
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+
+template <int MODE, int NQ, int FORMULA = 0, bool WIN = false, bool LDSY = false>
+__device__ __forceinline__ void eval_batch_from(const G1Dev& g, const double (&q)[NQ], double (&out)[NQ],
+                                                double extrap, const double* ytab)
 {
+    // ytab (mode 0): the Y table -- g.y in HBM/L2, or a workgroup's LDS copy of it (kept a plain parameter so that
+    // the compiler can see the address space after inlining and emit ds_read for the LDS copy)
     double qs[NQ];
     int l[NQ];
     bool oor[NQ];
@@ -129,7 +133,15 @@ __device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ]
             xr[k] = b;
         }
 #pragma unroll
-        for (int k = 0; k < NQ; ++k) yp[k] = *reinterpret_cast<const ypair*>(g.y + l[k]);
+        for (int k = 0; k < NQ; ++k) {
+            if constexpr (LDSY) {   // explicit LDS address space: ds_read2_b64 instead of a flat load
+                const lds_cdouble* p = (const lds_cdouble*)(ytab + l[k]);
+                yp[k].a = p[0];
+                yp[k].b = p[1];
+            } else {
+                yp[k] = *reinterpret_cast<const ypair*>(ytab + l[k]);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NQ; ++k) out[k] = blend(xl[k], yp[k].a, xr[k], yp[k].b, qs[k]);
     } else if constexpr (MODE == 3) {
@@ -204,6 +216,12 @@ __device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ]
     for (int k = 0; k < NQ; ++k) {
         if (oor[k]) out[k] = (q[k] != q[k]) ? __builtin_nan("") : extrap;
     }
+}
+
+template <int MODE, int NQ, int FORMULA = 0, bool WIN = false>
+__device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ], double (&out)[NQ], double extrap)
+{
+    eval_batch_from<MODE, NQ, FORMULA, WIN>(g, q, out, extrap, g.y);
 }
 
 #ifndef MI_SWEEP_BINS
@@ -302,6 +320,58 @@ __global__ __launch_bounds__(BLOCK) void interp1_vec_kernel(G1Dev g, const doubl
                 yq[nq - 1] = r1[0];
             }
         }
+    }
+}
+
+// ---- small tables: the whole Y table in LDS --------------------------------------------------------------
+// A table of up to 16 K nodes (128 KiB) fits one CU's LDS.  Unordered queries over such a table are bound by the
+// L2 request rate in the streaming kernel (one L2 hit per query: 0.6 ms per 1e8 queries); from LDS the two-node read
+// is a ds_read2_b64 and the kernel runs at the streaming rate.  One 1024-lane workgroup copies the table (L2 hits)
+// and then evaluates kLdsQueriesPerBlock queries, so the copy is a few per cent of the block's traffic; the grid is
+// full-size (one workgroup per chunk), as for the streaming kernel.  Arithmetic = eval_batch: bit-identical.
+constexpr int kLdsBlock = 1024;
+constexpr size_t kLdsMaxTableBytes = 128 * 1024;
+constexpr size_t kLdsMinTableBytes = 32 * 1024;   // smaller tables live in L1: the streaming kernel is as fast
+constexpr size_t kLdsQueriesPerBlock = 1u << 17;
+template <int FORMULA>
+__global__ __launch_bounds__(kLdsBlock) void interp1_lds_kernel(G1Dev g, const double* __restrict__ xq,
+                                                                double* __restrict__ yq, size_t nq, double extrap,
+                                                                ProbeArgs probe)
+{
+    extern __shared__ __attribute__((aligned(16))) double ys[];
+    if (probe.host_mailbox && blockIdx.x == 0 && threadIdx.x < 64) order_probe_wave(probe);   // for the next call
+    for (int i = threadIdx.x; i <= g.n; i += kLdsBlock) ys[i] = g.y[i];     // n + 1 entries (padding node)
+    __syncthreads();
+    const size_t q0 = (size_t)blockIdx.x * kLdsQueriesPerBlock;
+    const size_t q1 = min(nq, q0 + kLdsQueriesPerBlock);
+    const size_t nvec = (q1 - q0) >> 1;                                     // q0 is even: 16-B aligned vectors
+    const d2* in = reinterpret_cast<const d2*>(xq + q0);
+    d2* out = reinterpret_cast<d2*>(yq + q0);
+    size_t v = threadIdx.x;
+    for (; v + kLdsBlock < nvec; v += 2 * kLdsBlock) {                      // two vectors (four queries) per lane per trip
+        const d2 a = __builtin_nontemporal_load(in + v), b = __builtin_nontemporal_load(in + v + kLdsBlock);
+        const double q[4] = {a.x, a.y, b.x, b.y};
+        double r[4];
+        eval_batch_from<0, 4, FORMULA, false, true>(g, q, r, extrap, ys);
+        d2 o0, o1;
+        o0.x = r[0]; o0.y = r[1]; o1.x = r[2]; o1.y = r[3];
+        __builtin_nontemporal_store(o0, out + v);
+        __builtin_nontemporal_store(o1, out + v + kLdsBlock);
+    }
+    for (; v < nvec; v += kLdsBlock) {
+        const d2 a = __builtin_nontemporal_load(in + v);
+        const double q[2] = {a.x, a.y};
+        double r[2];
+        eval_batch_from<0, 2, FORMULA, false, true>(g, q, r, extrap, ys);
+        d2 o;
+        o.x = r[0]; o.y = r[1];
+        __builtin_nontemporal_store(o, out + v);
+    }
+    if (((q1 - q0) & 1) && threadIdx.x == 0) {                              // odd tail element of the last chunk
+        const double q[1] = {xq[q1 - 1]};
+        double r[1];
+        eval_batch_from<0, 1, FORMULA, false, true>(g, q, r, extrap, ys);
+        yq[q1 - 1] = r[0];
     }
 }
 
@@ -505,6 +575,29 @@ mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, size_t table_bytes, const dou
     const size_t ntiles = nq / kSweepTile;
     const bool sweep_ok = ctx->query_order != MI_QUERIES_ORDERED && table_bytes >= (5u << 20) &&
                           ntiles >= (size_t)cus * 4 && std::isfinite(d.xmax - d.xmin) && (d.xmax - d.xmin) > 0.0;
+    if constexpr (MODE == 0) {
+        // Whole table in LDS: unordered queries over a table that outgrows L1 (32 KiB) but fits LDS (128 KiB).
+        // scripts/gpu_small_table_timing.py, 1e8 queries: random 0.516 -> 0.287 ms at 10-16 K nodes; sorted queries are
+        // better off in the streaming kernel (0.25 vs 0.29 ms), so AUTO follows the previous call's probe verdict here
+        // too (the first call takes the LDS kernel, which is never far off).
+        const size_t ybytes = ((size_t)d.n + 1) * sizeof(double);
+        if (ctx->query_order != MI_QUERIES_ORDERED && ybytes > kLdsMinTableBytes && ybytes <= kLdsMaxTableBytes &&
+            nq >= 8 * kLdsQueriesPerBlock && std::isfinite(d.xmax - d.xmin) && (d.xmax - d.xmin) > 0.0) {
+            ProbeArgs probe{};
+            if (ctx->query_order == MI_QUERIES_AUTO) {
+                const int predicted = *reinterpret_cast<volatile int*>(ctx->probe_host);
+                probe = ProbeArgs{xq, nq, d.xmin, (double)kSweepBins / (d.xmax - d.xmin), nullptr, ctx->probe_host_dev};
+                if (predicted == 1) return launch_vec<MODE, FORMULA>(ctx, d, xq, yq, nq, extrap, nullptr, probe);
+            }
+            MI_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&interp1_lds_kernel<FORMULA>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMaxTableBytes));
+            const size_t grid = (nq + kLdsQueriesPerBlock - 1) / kLdsQueriesPerBlock;
+            hipLaunchKernelGGL((interp1_lds_kernel<FORMULA>), dim3((unsigned)grid), dim3(kLdsBlock), ybytes, ctx->stream, d, xq,
+                               yq, nq, extrap, probe);
+            MI_LAUNCH_CHECK(ctx, "interp1 LDS-table kernel");
+            return MI_OK;
+        }
+    }
     if (!sweep_ok) return launch_vec<MODE, FORMULA>(ctx, d, xq, yq, nq, extrap);
 
     const double bscale = (double)kSweepBins / (d.xmax - d.xmin);

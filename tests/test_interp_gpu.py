@@ -193,6 +193,42 @@ def test_explicit_grids_with_analytic_guess_are_bit_exact_around_every_node(mi_c
         assert _eq(g.interp(_t(q)).cpu().numpy(), oracle.interp1_bracket(X, Y, q)), name
 
 
+@pytest.mark.parametrize("n", [3, 1000, 4096, 10_000, 16_383, 16_384])
+def test_small_table_lds_path_equals_streaming_path(mi_ctx, n):
+    """Tables of at most 16 K nodes (closed-form abscissae) are copied into LDS by each workgroup when the query
+    set is large and not declared ordered; the result must be bit-identical to the streaming kernel (ORDERED hint)
+    and to the oracle, ragged/odd sizes, NaN and out-of-range queries included.  16 384 nodes + the padding node is
+    one entry more than LDS holds and must fall back to the streaming kernel."""
+    import armadillocudalinearinterpolation_amd as mi
+    import torch
+    X = np.linspace(-1.5, 2.25, n)
+    Y = np.cos(3 * X) + 0.1 * X
+    grid = mi.Grid1.from_nodes(mi_ctx, X, Y)
+    assert grid.info()["mode"] == 0
+    for nq in (8 * (1 << 17), 9 * (1 << 17) + 4097, 8 * (1 << 17) + 1):
+        g = torch.Generator(device="cuda:0").manual_seed(n + nq)
+        xq = torch.rand(nq, dtype=torch.float64, device="cuda:0", generator=g) * 3.9 - 1.6
+        xq[:5] = torch.tensor([float("nan"), -7.0, 7.0, float(X[0]), float(X[-1])], dtype=torch.float64)
+        xq[-2:] = torch.tensor([float(X[-1]), float("nan")], dtype=torch.float64)
+        try:
+            mi_ctx.set_query_order(1)                                  # unordered: LDS-table kernel where it applies
+            a = grid.interp(xq, extrap=4.5)
+            mi_ctx.set_query_order(2)                                  # streaming kernel
+            b = grid.interp(xq, extrap=4.5)
+            mi_ctx.set_query_order(0)                                  # auto, twice: first call, then predicted
+            c = grid.interp(xq, extrap=4.5)
+            mi_ctx.synchronize()
+            d = grid.interp(xq, extrap=4.5)
+        finally:
+            mi_ctx.set_query_order(0)
+        for other in (b, c, d):
+            assert torch.equal(a.view(torch.int64), other.view(torch.int64))
+        idx = torch.cat([torch.arange(0, 3000, device="cuda:0"), torch.arange(0, nq, 1009, device="cuda:0"),
+                         torch.arange(nq - 3000, nq, device="cuda:0")])
+        ref = oracle.interp1_bracket(X, Y, xq[idx].cpu().numpy(), extrap=4.5)
+        assert np.array_equal(a[idx].cpu().numpy(), ref, equal_nan=True)
+
+
 def test_queries_on_nodes_and_cell_midpoints(mi_ctx):
     import armadillocudalinearinterpolation_amd as mi
     rng = np.random.default_rng(8)
