@@ -103,12 +103,27 @@ __device__ __forceinline__ double unode(const G1Dev& g, int i)
 // lanes that need it (unordered queries: every gather is an L2 request).
 typedef __attribute__((address_space(3))) const double lds_cdouble;
 
+// node i of an {x,y} table that lives in global memory, or (LDSY) in a workgroup's LDS copy (explicit address space)
+template <bool LDSY>
+__device__ __forceinline__ d2 load_node(const double* tab, int i)
+{
+    d2 v;
+    if constexpr (LDSY) {
+        const lds_cdouble* p = (const lds_cdouble*)(tab + 2 * (size_t)i);
+        v.x = p[0];
+        v.y = p[1];
+    } else {
+        v = reinterpret_cast<const d2*>(tab)[i];
+    }
+    return v;
+}
+
 template <int MODE, int NQ, int FORMULA = 0, bool WIN = false, bool LDSY = false>
 __device__ __forceinline__ void eval_batch_from(const G1Dev& g, const double (&q)[NQ], double (&out)[NQ],
                                                 double extrap, const double* ytab)
 {
-    // ytab (mode 0): the Y table -- g.y in HBM/L2, or a workgroup's LDS copy of it (kept a plain parameter so that
-    // the compiler can see the address space after inlining and emit ds_read for the LDS copy)
+    // ytab: the table -- g.y (mode 0) or g.nodes (mode 3) in HBM/L2, or (LDSY) a workgroup's LDS copy of it;
+    // modes 1 and 2 read g.nodes directly
     double qs[NQ];
     int l[NQ];
     bool oor[NQ];
@@ -156,13 +171,13 @@ __device__ __forceinline__ void eval_batch_from(const G1Dev& g, const double (&q
         }
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
-            if constexpr (WIN) nm[k] = g.nodes[max(l[k] - 1, 0)];
-            n0[k] = g.nodes[l[k]];
-            n1[k] = g.nodes[l[k] + 1];        // index n is the padding node
+            if constexpr (WIN) nm[k] = load_node<LDSY>(ytab, max(l[k] - 1, 0));
+            n0[k] = load_node<LDSY>(ytab, l[k]);
+            n1[k] = load_node<LDSY>(ytab, l[k] + 1);        // index n is the padding node
         }
         if constexpr (!WIN) {   // fetch node G-1 only where it is needed (one dependent gather, no loop)
 #pragma unroll
-            for (int k = 0; k < NQ; ++k) nm[k] = (qs[k] < n0[k].x) ? g.nodes[max(l[k] - 1, 0)] : n0[k];
+            for (int k = 0; k < NQ; ++k) nm[k] = (qs[k] < n0[k].x) ? load_node<LDSY>(ytab, max(l[k] - 1, 0)) : n0[k];
         }
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
@@ -221,7 +236,7 @@ __device__ __forceinline__ void eval_batch_from(const G1Dev& g, const double (&q
 template <int MODE, int NQ, int FORMULA = 0, bool WIN = false>
 __device__ __forceinline__ void eval_batch(const G1Dev& g, const double (&q)[NQ], double (&out)[NQ], double extrap)
 {
-    eval_batch_from<MODE, NQ, FORMULA, WIN>(g, q, out, extrap, g.y);
+    eval_batch_from<MODE, NQ, FORMULA, WIN>(g, q, out, extrap, MODE == 0 ? g.y : reinterpret_cast<const double*>(g.nodes));
 }
 
 #ifndef MI_SWEEP_BINS
@@ -323,24 +338,29 @@ __global__ __launch_bounds__(BLOCK) void interp1_vec_kernel(G1Dev g, const doubl
     }
 }
 
-// ---- small tables: the whole Y table in LDS --------------------------------------------------------------
-// A table of up to 16 K nodes (128 KiB) fits one CU's LDS.  Unordered queries over such a table are bound by the
+// ---- small tables: the whole table in LDS ----------------------------------------------------------------
+// A table of up to 128 KiB (16 K nodes of a closed-form grid, 8 K {x,y} nodes of a centred-guess grid) fits one CU's LDS.  Unordered queries over such a table are bound by the
 // L2 request rate in the streaming kernel (one L2 hit per query: 0.6 ms per 1e8 queries); from LDS the two-node read
 // is a ds_read2_b64 and the kernel runs at the streaming rate.  One 1024-lane workgroup copies the table (L2 hits)
 // and then evaluates kLdsQueriesPerBlock queries, so the copy is a few per cent of the block's traffic; the grid is
 // full-size (one workgroup per chunk), as for the streaming kernel.  Arithmetic = eval_batch: bit-identical.
 constexpr int kLdsBlock = 1024;
 constexpr size_t kLdsMaxTableBytes = 128 * 1024;
-constexpr size_t kLdsMinTableBytes = 32 * 1024;   // smaller tables live in L1: the streaming kernel is as fast
+constexpr size_t kLdsMinTableBytes0 = 32 * 1024;  // mode 0: smaller tables live in L1 and one gather per query streams as fast
+constexpr size_t kLdsMinTableBytes3 = 2 * 1024;   // mode 3: three gathers per query are TA-bound even from L1 (0.44 vs 0.28 ms)
 constexpr size_t kLdsQueriesPerBlock = 1u << 17;
-template <int FORMULA>
+template <int MODE, int FORMULA>
 __global__ __launch_bounds__(kLdsBlock) void interp1_lds_kernel(G1Dev g, const double* __restrict__ xq,
                                                                 double* __restrict__ yq, size_t nq, double extrap,
                                                                 ProbeArgs probe)
 {
     extern __shared__ __attribute__((aligned(16))) double ys[];
     if (probe.host_mailbox && blockIdx.x == 0 && threadIdx.x < 64) order_probe_wave(probe);   // for the next call
-    for (int i = threadIdx.x; i <= g.n; i += kLdsBlock) ys[i] = g.y[i];     // n + 1 entries (padding node)
+    {   // n + 1 entries (padding node) of 8 B (mode 0: Y) or 16 B (mode 3: {x,y})
+        const double* src = MODE == 0 ? g.y : reinterpret_cast<const double*>(g.nodes);
+        const int words = (MODE == 0 ? 1 : 2) * (g.n + 1);
+        for (int i = threadIdx.x; i < words; i += kLdsBlock) ys[i] = src[i];
+    }
     __syncthreads();
     const size_t q0 = (size_t)blockIdx.x * kLdsQueriesPerBlock;
     const size_t q1 = min(nq, q0 + kLdsQueriesPerBlock);
@@ -352,7 +372,7 @@ __global__ __launch_bounds__(kLdsBlock) void interp1_lds_kernel(G1Dev g, const d
         const d2 a = __builtin_nontemporal_load(in + v), b = __builtin_nontemporal_load(in + v + kLdsBlock);
         const double q[4] = {a.x, a.y, b.x, b.y};
         double r[4];
-        eval_batch_from<0, 4, FORMULA, false, true>(g, q, r, extrap, ys);
+        eval_batch_from<MODE, 4, FORMULA, true, true>(g, q, r, extrap, ys);
         d2 o0, o1;
         o0.x = r[0]; o0.y = r[1]; o1.x = r[2]; o1.y = r[3];
         __builtin_nontemporal_store(o0, out + v);
@@ -362,7 +382,7 @@ __global__ __launch_bounds__(kLdsBlock) void interp1_lds_kernel(G1Dev g, const d
         const d2 a = __builtin_nontemporal_load(in + v);
         const double q[2] = {a.x, a.y};
         double r[2];
-        eval_batch_from<0, 2, FORMULA, false, true>(g, q, r, extrap, ys);
+        eval_batch_from<MODE, 2, FORMULA, true, true>(g, q, r, extrap, ys);
         d2 o;
         o.x = r[0]; o.y = r[1];
         __builtin_nontemporal_store(o, out + v);
@@ -370,7 +390,7 @@ __global__ __launch_bounds__(kLdsBlock) void interp1_lds_kernel(G1Dev g, const d
     if (((q1 - q0) & 1) && threadIdx.x == 0) {                              // odd tail element of the last chunk
         const double q[1] = {xq[q1 - 1]};
         double r[1];
-        eval_batch_from<0, 1, FORMULA, false, true>(g, q, r, extrap, ys);
+        eval_batch_from<MODE, 1, FORMULA, true, true>(g, q, r, extrap, ys);
         yq[q1 - 1] = r[0];
     }
 }
@@ -575,13 +595,13 @@ mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, size_t table_bytes, const dou
     const size_t ntiles = nq / kSweepTile;
     const bool sweep_ok = ctx->query_order != MI_QUERIES_ORDERED && table_bytes >= (5u << 20) &&
                           ntiles >= (size_t)cus * 4 && std::isfinite(d.xmax - d.xmin) && (d.xmax - d.xmin) > 0.0;
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 0 || MODE == 3) {
         // Whole table in LDS: unordered queries over a table that outgrows L1 (32 KiB) but fits LDS (128 KiB).
         // scripts/gpu_small_table_timing.py, 1e8 queries: random 0.516 -> 0.287 ms at 10-16 K nodes; sorted queries are
         // better off in the streaming kernel (0.25 vs 0.29 ms), so AUTO follows the previous call's probe verdict here
         // too (the first call takes the LDS kernel, which is never far off).
-        const size_t ybytes = ((size_t)d.n + 1) * sizeof(double);
-        if (ctx->query_order != MI_QUERIES_ORDERED && ybytes > kLdsMinTableBytes && ybytes <= kLdsMaxTableBytes &&
+        const size_t ybytes = ((size_t)d.n + 1) * (MODE == 0 ? sizeof(double) : sizeof(d2));
+        if (ctx->query_order != MI_QUERIES_ORDERED && ybytes > (MODE == 0 ? kLdsMinTableBytes0 : kLdsMinTableBytes3) && ybytes <= kLdsMaxTableBytes &&
             nq >= 8 * kLdsQueriesPerBlock && std::isfinite(d.xmax - d.xmin) && (d.xmax - d.xmin) > 0.0) {
             ProbeArgs probe{};
             if (ctx->query_order == MI_QUERIES_AUTO) {
@@ -589,10 +609,10 @@ mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, size_t table_bytes, const dou
                 probe = ProbeArgs{xq, nq, d.xmin, (double)kSweepBins / (d.xmax - d.xmin), nullptr, ctx->probe_host_dev};
                 if (predicted == 1) return launch_vec<MODE, FORMULA>(ctx, d, xq, yq, nq, extrap, nullptr, probe);
             }
-            MI_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&interp1_lds_kernel<FORMULA>),
+            MI_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&interp1_lds_kernel<MODE, FORMULA>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMaxTableBytes));
             const size_t grid = (nq + kLdsQueriesPerBlock - 1) / kLdsQueriesPerBlock;
-            hipLaunchKernelGGL((interp1_lds_kernel<FORMULA>), dim3((unsigned)grid), dim3(kLdsBlock), ybytes, ctx->stream, d, xq,
+            hipLaunchKernelGGL((interp1_lds_kernel<MODE, FORMULA>), dim3((unsigned)grid), dim3(kLdsBlock), ybytes, ctx->stream, d, xq,
                                yq, nq, extrap, probe);
             MI_LAUNCH_CHECK(ctx, "interp1 LDS-table kernel");
             return MI_OK;

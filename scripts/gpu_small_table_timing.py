@@ -15,9 +15,10 @@ def main():
     u = synth.splitmix_uniform(0x5EED0003, nq, "cuda:0")
     su = torch.sort(u).values.contiguous()
     out = torch.empty_like(u)
-    for ng in (100, 1000, 10_000, 16_000, 20_000, 100_000):
-        X = np.arange(ng) / (ng - 1)
-        g = mi.Grid1.from_nodes(ctx, X, np.sin(2 * np.pi * X) + 0.5 * X)
+    cases = [(ng, "closed") for ng in (100, 1000, 10_000, 16_000, 20_000, 100_000)] + [(ng, "jitter") for ng in (1000, 4000, 8000, 10_000, 100_000)]
+    for ng, kind in cases:
+        X = np.arange(ng) / (ng - 1) if kind == "closed" else (np.arange(ng) + 0.5 * np.random.default_rng(ng).random(ng)) / ng
+        g = mi.Grid1.from_nodes(ctx, X, np.sin(2 * np.pi * X) + 0.5 * X, sanitise=False)
         row = []
         for qname, q in (("random", u), ("sorted", su)):
             for hint in (0, 2):
@@ -32,7 +33,7 @@ def main():
                 ctx.synchronize()
                 row.append("%s/%s %.4f" % (qname, "auto" if hint == 0 else "stream", t.elapsed_ms() / 5))
         ctx.set_query_order(0)
-        print("ng %7d : %s" % (ng, "  ".join(row)), flush=True)
+        print("ng %7d %-6s mode %d : %s" % (ng, kind, g.info()["mode"], "  ".join(row)), flush=True)
 
 
 if __name__ == "__main__":

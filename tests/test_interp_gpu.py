@@ -193,18 +193,24 @@ def test_explicit_grids_with_analytic_guess_are_bit_exact_around_every_node(mi_c
         assert _eq(g.interp(_t(q)).cpu().numpy(), oracle.interp1_bracket(X, Y, q)), name
 
 
-@pytest.mark.parametrize("n", [3, 1000, 4096, 10_000, 16_383, 16_384])
-def test_small_table_lds_path_equals_streaming_path(mi_ctx, n):
+@pytest.mark.parametrize("n,kind", [(3, "closed"), (1000, "closed"), (4096, "closed"), (10_000, "closed"),
+                                    (16_383, "closed"), (16_384, "closed"), (2049, "jitter"), (5000, "jitter"),
+                                    (8191, "jitter"), (8192, "jitter")])
+def test_small_table_lds_path_equals_streaming_path(mi_ctx, n, kind):
     """Tables of at most 16 K nodes (closed-form abscissae) are copied into LDS by each workgroup when the query
     set is large and not declared ordered; the result must be bit-identical to the streaming kernel (ORDERED hint)
     and to the oracle, ragged/odd sizes, NaN and out-of-range queries included.  16 384 nodes + the padding node is
-    one entry more than LDS holds and must fall back to the streaming kernel."""
+    one entry more than LDS holds and must fall back to the streaming kernel.  The same for {x,y} tables with a
+    centred guess (mode 3, at most 8191 nodes)."""
     import armadillocudalinearinterpolation_amd as mi
     import torch
-    X = np.linspace(-1.5, 2.25, n)
+    if kind == "closed":
+        X = np.linspace(-1.5, 2.25, n)
+    else:
+        X = -1.5 + 3.75 * (np.arange(n) + 0.5 * oracle.splitmix_uniform(n, n)) / n
     Y = np.cos(3 * X) + 0.1 * X
-    grid = mi.Grid1.from_nodes(mi_ctx, X, Y)
-    assert grid.info()["mode"] == 0
+    grid = mi.Grid1.from_nodes(mi_ctx, X, Y, sanitise=False)
+    assert grid.info()["mode"] == (0 if kind == "closed" else 3)
     for nq in (8 * (1 << 17), 9 * (1 << 17) + 4097, 8 * (1 << 17) + 1):
         g = torch.Generator(device="cuda:0").manual_seed(n + nq)
         xq = torch.rand(nq, dtype=torch.float64, device="cuda:0", generator=g) * 3.9 - 1.6
