@@ -1,0 +1,90 @@
+"""Differential fuzz of mi_interp1_f64_dev against the CPU oracle (run on the GPU box; not part of the test suite).
+Random grid families x sizes x query sets x order hints; every result must equal oracle.interp1_bracket bit for bit."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import oracle
+
+
+def grid_family(rng, kind, n):
+    i = np.arange(n, dtype=np.float64)
+    if kind == "linspace":
+        a, b = sorted(rng.uniform(-1e3, 1e3, 2))
+        return np.linspace(a, b + 1e-3, n)
+    if kind == "arange":
+        return rng.uniform(-5, 5) + rng.uniform(1e-6, 2.0) * i
+    if kind == "jitter":
+        return rng.uniform(-3, 3) + rng.uniform(0.1, 4.0) * (i + rng.uniform(0.05, 0.95) * rng.random(n)) / n
+    if kind == "wide_jitter":
+        return np.unique(np.sort((i + rng.uniform(1.1, 3.0) * rng.random(n)) / n))
+    if kind == "power":
+        return np.unique((i / max(n - 1, 1)) ** rng.uniform(1.5, 4.0))
+    if kind == "cumsum":
+        return np.cumsum(rng.random(n) ** rng.integers(1, 6) + 1e-9)
+    if kind == "stretched":
+        return (i / max(n - 1, 1)) ** (1.0 + rng.uniform(-3e-5, 3e-5)) * rng.uniform(0.5, 50.0)
+    raise ValueError(kind)
+
+
+def main():
+    import armadillocudalinearinterpolation_amd as mi
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    ctx = mi.Context(0)
+    t0, cases, modes = time.time(), 0, {}
+    kinds = ["linspace", "arange", "jitter", "wide_jitter", "power", "cumsum", "stretched"]
+    sizes = [2, 3, 7, 64, 1000, 4095, 8191, 8192, 16383, 16384, 40000, 700000, 1200000]
+    while time.time() - t0 < budget:
+        kind = kinds[rng.integers(len(kinds))]
+        n = int(sizes[rng.integers(len(sizes))])
+        X = np.ascontiguousarray(grid_family(rng, kind, n))
+        if X.size < 2 or not np.all(np.diff(X) > 0):
+            continue
+        Y = np.sin(X * rng.uniform(0.1, 3.0) / max(abs(X[-1]), 1.0)) * rng.uniform(0.5, 1e3) + rng.uniform(-1, 1) * X
+        g = mi.Grid1.from_nodes(ctx, X, Y, sanitise=False)
+        mode = g.info()["mode"]
+        modes[mode] = modes.get(mode, 0) + 1
+        big = rng.random() < 0.5
+        nq = int(rng.choice([1, 2, 5, 1000, 65537])) if not big else int(rng.choice([1 << 20, (1 << 20) + 1, 17_000_000 + int(rng.integers(0, 20000))]))
+        span = X[-1] - X[0]
+        q = rng.random(nq) * span * 1.04 + X[0] - 0.02 * span
+        style = rng.integers(4)
+        if style == 1:
+            q = np.sort(q)
+        elif style == 2 and nq > 10:                       # piles on nodes and their neighbours
+            pick = X[rng.integers(0, X.size, nq)]
+            q = np.where(rng.random(nq) < 0.5, pick, np.nextafter(pick, rng.choice([-np.inf, np.inf])))
+        elif style == 3 and nq > 10:                       # clustered in a narrow band
+            q = X[0] + span * (0.3 + 0.01 * rng.random(nq))
+        if nq > 6:
+            q[:6] = [np.nan, np.inf, -np.inf, X[0], X[-1], np.nextafter(X[-1], np.inf)]
+        tq = torch.from_numpy(q).cuda()
+        ref = None
+        for hint in (0, 1, 2, 0):
+            ctx.set_query_order(hint)
+            out = g.interp(tq, extrap=-123.25)
+            ctx.synchronize()
+            if ref is None:
+                sel = np.arange(nq) if nq <= 300000 else np.concatenate([np.arange(5000), rng.integers(0, nq, 200000), np.arange(nq - 5000, nq)])
+                ref = oracle.interp1_bracket(X, Y, q[sel], extrap=-123.25, nthreads=8)
+                first = out
+                if not np.array_equal(out[torch.from_numpy(sel).cuda()].cpu().numpy(), ref, equal_nan=True):
+                    print("MISMATCH vs oracle", kind, n, nq, mode, style, hint, flush=True)
+                    sys.exit(1)
+            elif not torch.equal(out.view(torch.int64), first.view(torch.int64)):
+                print("MISMATCH between hints", kind, n, nq, mode, style, hint, flush=True)
+                sys.exit(1)
+        ctx.set_query_order(0)
+        cases += 1
+        del g
+    print("fuzz ok: %d cases in %.0f s, table modes seen %s" % (cases, time.time() - t0, dict(sorted(modes.items()))), flush=True)
+
+
+if __name__ == "__main__":
+    main()
