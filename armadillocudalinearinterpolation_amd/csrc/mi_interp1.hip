@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cmath>
 #include <new>
+#include <cstdlib>
 #include <vector>
 
 #include "mi_common.hpp"
@@ -593,7 +594,14 @@ mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, size_t table_bytes, const dou
     // 16-32 MB, still 1.05x at 512 MB) and there are enough tiles to keep every CU busy for several sweeps; ordered query sets are detected on the device (or declared by the caller).
     const unsigned cus = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256);
     const size_t ntiles = nq / kSweepTile;
-    const bool sweep_ok = ctx->query_order != MI_QUERIES_ORDERED && table_bytes >= (5u << 20) &&
+    // {x,y} tables with the centred guess (mode 3) gain from the sweep much earlier: ordering a tile by region makes
+    // the lanes of a wave share lines, and three gathers per query are expensive in the streaming kernel
+    // (profiles/r01_sweep_vs_stream_midsize_tables.log: 1.3x at 0.16-0.5 MB, 1.05-1.17x at 1-2.4 MB, 0.92-0.99x between
+    // 2.8 and 3.6 MB, 1.12-1.25x from 4 MB); closed-form tables gain 5-7 % between 0.26 and 1.6 MB, not taken.
+    bool size_ok = table_bytes >= ((size_t)5 << 20);
+    if (MODE == 3) size_ok = table_bytes > kLdsMaxTableBytes && !(table_bytes > 2600000 && table_bytes < 3900000);
+    if (const char* env = getenv("MI_SWEEP_MIN_BYTES")) size_ok = table_bytes >= (size_t)strtoull(env, nullptr, 10);   // tuning hook
+    const bool sweep_ok = ctx->query_order != MI_QUERIES_ORDERED && size_ok &&
                           ntiles >= (size_t)cus * 4 && std::isfinite(d.xmax - d.xmin) && (d.xmax - d.xmin) > 0.0;
     if constexpr (MODE == 0 || MODE == 3) {
         // Whole table in LDS: unordered queries over a table that outgrows L1 (32 KiB) but fits LDS (128 KiB).
