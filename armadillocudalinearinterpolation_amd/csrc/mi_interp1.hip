@@ -1,10 +1,19 @@
-// 1-D table interpolation on MI355X (gfx950): HBM-resident tables + the
-// streaming gather-and-blend kernels.  Hand-written HIP; bandwidth-bound
-// (8 B in + 8 B out per query), no MFMA.
+// 1-D table interpolation on MI355X (gfx950): HBM-resident tables and the gather-and-blend kernels behind
+// mi_interp1_f64_dev.  Hand-written HIP; memory-bound (8 B in + 8 B out per query), no MFMA.
 //
 // Semantics: include/mi355_interp.h ("fp64 blend") == oracle/interp_oracle.c.
 // The file is compiled with -ffp-contract=off so that every product and sum of
 // the blend rounds separately, exactly like the oracle.
+//
+// Kernels (all share eval_batch_from, so their results are bit-identical; launch_mode picks one):
+//   interp1_vec_kernel    streaming: full-size grid, two 16-B vectors per lane.  Ordered / clustered queries,
+//                         small tables, tails.
+//   interp1_sweep_kernel  region sweep: persistent workgroups order a 16 K-query tile by table region in LDS so
+//                         that the whole chip gathers from the same part of the table at the same time.
+//                         Unordered queries over tables that outgrow L2 (and mid-size {x,y} tables).
+//   interp1_lds_kernel    the whole table in LDS (<= 128 KiB): unordered queries over small tables.
+//   interp1_scalar_kernel unaligned pointers.
+//   interp1_order_probe   1024-sample test "are the queries already ordered?" (also inlined into the kernels).
 //
 // Table layouts (all with one padding node so that node l+1 is always
 // readable):
@@ -20,10 +29,12 @@
 //           these forms (checked node by node at build time; the last node may be
 //           an exception, as linspace pins it) is stored this way too: half the
 //           table bytes and one 16-B gather per query instead of 32 B.
-//   mode 1  explicit + guess   {x,y}[n+1]            16 B/node, one 32-B gather/query
+//   mode 1  explicit + guess   {x,y}[n+1]            16 B/node, analytic guess + bounded walk
+//   mode 3  explicit + centred guess, same storage: the grid stays within one cell of a straight line, origin and
+//           slope are chosen so that the guess equals i at every node (verified), the bracket is G-1 or G: no walk
 //   mode 2  explicit + buckets {x,y}[n+1] + u32[nb+1] bucket index, then a
 //           binary search confined to the bucket's node range
-// Mode 1 is chosen when the analytic guess g(q) = (q-xmin)*(n-1)/(xmax-xmin)
+// Mode 1/3 is chosen when the analytic guess g(q) = (q-xmin)*(n-1)/(xmax-xmin)
 // provably lands within a few nodes of the bracket for every possible query
 // (verified against every node at build time); otherwise mode 2.
 #include <algorithm>
