@@ -106,10 +106,10 @@ mi_status mi_ctx_set_query_order(mi_ctx* ctx, int order)
 mi_status mi_ctx_destroy(mi_ctx* ctx)
 {
     if (!ctx) return MI_OK;
-    hipSetDevice(ctx->device);
+    (void)hipSetDevice(ctx->device);
     for (int i = 0; i < 3; ++i)
-        if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
-    if (ctx->reduce_ws) hipFree(ctx->reduce_ws);
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->reduce_ws) (void)hipFree(ctx->reduce_ws);
     (void)hipStreamSynchronize(ctx->stream);   // a probe in flight may still write its mailbox
     if (ctx->probe_host) (void)hipHostFree(ctx->probe_host);
     delete ctx;
@@ -159,8 +159,8 @@ mi_status mi_timer_create(mi_ctx* ctx, mi_timer** out)
 mi_status mi_timer_destroy(mi_timer* t)
 {
     if (!t) return MI_OK;
-    hipEventDestroy(t->start);
-    hipEventDestroy(t->stop);
+    (void)hipEventDestroy(t->start);
+    (void)hipEventDestroy(t->stop);
     delete t;
     return MI_OK;
 }

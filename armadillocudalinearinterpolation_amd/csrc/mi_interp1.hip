@@ -858,7 +858,7 @@ mi_status build_explicit(mi_ctx* ctx, const std::vector<double>& xs, const std::
     }
     mi_status st = upload(ctx, &g->dev_nodes, nodes.data(), (n + 1) * sizeof(d2));
     if (st != MI_OK) {
-        if (g->dev_s) hipFree(g->dev_s);
+        if (g->dev_s) (void)hipFree(g->dev_s);
         delete g;
         return st;
     }
@@ -968,9 +968,9 @@ mi_status mi_grid1_create_uniform(mi_ctx* ctx, double x0, double dx, const doubl
 mi_status mi_grid1_destroy(mi_grid1* g)
 {
     if (!g) return MI_OK;
-    hipSetDevice(g->ctx->device);
-    if (g->dev_nodes) hipFree(g->dev_nodes);
-    if (g->dev_s) hipFree(g->dev_s);
+    (void)hipSetDevice(g->ctx->device);
+    if (g->dev_nodes) (void)hipFree(g->dev_nodes);
+    if (g->dev_s) (void)hipFree(g->dev_s);
     delete g;
     return MI_OK;
 }

@@ -259,9 +259,9 @@ bool want_quads(unsigned flags, size_t ny, size_t nx)
 void destroy(mi_grid2* g)
 {
     if (!g) return;
-    if (g->dev_x) hipFree(g->dev_x);
-    if (g->dev_y) hipFree(g->dev_y);
-    if (g->dev_z) hipFree(g->dev_z);
+    if (g->dev_x) (void)hipFree(g->dev_x);
+    if (g->dev_y) (void)hipFree(g->dev_y);
+    if (g->dev_z) (void)hipFree(g->dev_z);
     delete g;
 }
 
@@ -325,7 +325,7 @@ mi_status mi_grid2_create_uniform(mi_ctx* ctx, double x0, double dx, size_t nx, 
 
 mi_status mi_grid2_destroy(mi_grid2* g)
 {
-    if (g) hipSetDevice(g->ctx->device);
+    if (g) (void)hipSetDevice(g->ctx->device);
     destroy(g);
     return MI_OK;
 }

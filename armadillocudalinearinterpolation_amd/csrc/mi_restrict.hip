@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void mean_stage2_kernel(const Partials* __r
     const unsigned c = wave_sum_u(cnt);
     if (lane == 0) lds_cnt[wave] = c;
     __syncthreads();
-    if (threadIdx.x < nspikes) {
+    if ((int)threadIdx.x < nspikes) {
         unsigned total = 0;
 #pragma unroll
         for (int w = 0; w < kBlock / 64; ++w) total += lds_cnt[w];
