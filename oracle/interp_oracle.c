@@ -283,8 +283,10 @@ void orc_interp2_bilinear_uniform(double x0, double dx, size_t nx, double y0, do
         if (qx != qx || qy != qy) { zq[i] = NAN; continue; }
         if (qx < x0 || qx > x_max || qy < y0 || qy > y_max) { zq[i] = extrap; continue; }
         long long lx = (long long)((qx - x0) * inv_dx), ly = (long long)((qy - y0) * inv_dy);
-        if (lx < 0) lx = 0; if (lx > lastx) lx = lastx;
-        if (ly < 0) ly = 0; if (ly > lasty) ly = lasty;
+        if (lx < 0) lx = 0;
+        if (lx > lastx) lx = lastx;
+        if (ly < 0) ly = 0;
+        if (ly > lasty) ly = lasty;
         while (lx > 0 && orc_unode(x0, dx, lx) > qx) --lx;
         while (lx < lastx && orc_unode(x0, dx, lx + 1) <= qx) ++lx;
         while (ly > 0 && orc_unode(y0, dy, ly) > qy) --ly;
