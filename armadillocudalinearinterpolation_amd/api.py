@@ -171,9 +171,12 @@ class Grid1:
               self._ctx._h)
         return out
 
-    def interp_host(self, xq, extrap=math.nan):
+    def interp_host(self, xq, extrap=math.nan, out=None):
         xq = _np64(xq)
-        out = np.empty_like(xq)
+        if out is None:
+            out = np.empty_like(xq)
+        elif out.dtype != np.float64 or out.size != xq.size or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a contiguous float64 array of the query size")
         check(self._L.mi_interp1_f64_host(self._ctx._h, self._h, _ptr(xq), _ptr(out), xq.size, float(extrap)),
               self._ctx._h)
         return out

@@ -31,6 +31,9 @@ struct mi_ctx {
     // MI_QUERIES_AUTO: the probe kernel also drops its verdict into a pinned host int (never waited for); the host
     // reads whatever is there at the next call and uses it only to PREDICT which kernel to launch -- either kernel
     // is correct on any input.  -1 = no verdict yet (both kernels are launched, gated on the device-side flag).
+    // host-convenience entry points overlap H2D, kernel and D2H of consecutive chunks: the copy back runs here
+    hipStream_t aux_stream = nullptr;   // created on first use
+    hipEvent_t aux_event = nullptr;
     int* probe_host = nullptr;       // host view
     int* probe_host_dev = nullptr;   // device view of the same int
 };
@@ -58,6 +61,7 @@ inline unsigned stream_grid(const mi_ctx* ctx, size_t work_items, unsigned block
 }
 
 mi_status ensure_scratch(mi_ctx* ctx, int slot, size_t bytes);
+mi_status ensure_aux_stream(mi_ctx* ctx);
 
 }  // namespace mi
 

@@ -38,6 +38,14 @@ mi_status ensure_scratch(mi_ctx* ctx, int slot, size_t bytes)
     return MI_OK;
 }
 
+mi_status ensure_aux_stream(mi_ctx* ctx)
+{
+    if (ctx->aux_stream) return MI_OK;
+    MI_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    MI_HIP(ctx, hipEventCreateWithFlags(&ctx->aux_event, hipEventDisableTiming));
+    return MI_OK;
+}
+
 }  // namespace mi
 
 extern "C" {
@@ -111,6 +119,8 @@ mi_status mi_ctx_destroy(mi_ctx* ctx)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->reduce_ws) (void)hipFree(ctx->reduce_ws);
     (void)hipStreamSynchronize(ctx->stream);   // a probe in flight may still write its mailbox
+    if (ctx->aux_event) (void)hipEventDestroy(ctx->aux_event);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->probe_host) (void)hipHostFree(ctx->probe_host);
     delete ctx;
     return MI_OK;

@@ -1015,11 +1015,44 @@ mi_status mi_interp1_f64_host(mi_ctx* ctx, const mi_grid1* g, const double* xq, 
     if (st != MI_OK) return st;
     st = mi::ensure_scratch(ctx, 1, bytes);
     if (st != MI_OK) return st;
-    MI_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], xq, bytes, hipMemcpyHostToDevice, ctx->stream));
-    st = mi_interp1_f64_dev(ctx, g, (const double*)ctx->scratch[0], (double*)ctx->scratch[1], nq, extrap);
+    // Chunks of 8 M queries: the copy back of chunk k (aux stream) overlaps the upload of chunk k+1 (main stream) --
+    // PCIe carries both directions at once (scripts/exp_pcie.hip: 0.8 GB each way 14 + 14 ms one after the other,
+    // 16.5 ms together); the kernel is 4 % of either copy.  Small calls keep the single-shot form.
+    const size_t chunk = (size_t)8 << 20;
+    if (nq <= 2 * chunk) {
+        MI_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], xq, bytes, hipMemcpyHostToDevice, ctx->stream));
+        st = mi_interp1_f64_dev(ctx, g, (const double*)ctx->scratch[0], (double*)ctx->scratch[1], nq, extrap);
+        if (st != MI_OK) return st;
+        MI_HIP(ctx, hipMemcpyAsync(yq, ctx->scratch[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
+        MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return MI_OK;
+    }
+    st = mi::ensure_aux_stream(ctx);
     if (st != MI_OK) return st;
-    MI_HIP(ctx, hipMemcpyAsync(yq, ctx->scratch[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // Asynchronous copies need page-locked host memory: pin the caller's arrays for the duration of the call (the
+    // runtime keeps the pinning of a range it has seen before, so this costs nothing from the second call on; a
+    // range that cannot be pinned, or is pinned already, simply takes the blocking path inside hipMemcpyAsync).
+    const bool pin_in = hipHostRegister(const_cast<double*>(xq), bytes, hipHostRegisterDefault) == hipSuccess;
+    const bool pin_out = hipHostRegister(yq, bytes, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+    const double* din = (const double*)ctx->scratch[0];
+    double* dout = (double*)ctx->scratch[1];
+    for (size_t off = 0; off < nq; off += chunk) {
+        const size_t m = std::min(chunk, nq - off);
+        MI_HIP(ctx, hipMemcpyAsync((void*)(din + off), xq + off, m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        st = mi_interp1_f64_dev(ctx, g, din + off, dout + off, m, extrap);
+        if (st != MI_OK) break;
+        MI_HIP(ctx, hipEventRecord(ctx->aux_event, ctx->stream));
+        MI_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_event, 0));
+        MI_HIP(ctx, hipMemcpyAsync(yq + off, dout + off, m * sizeof(double), hipMemcpyDeviceToHost, ctx->aux_stream));
+    }
+    hipError_t e1 = hipStreamSynchronize(ctx->stream), e2 = hipStreamSynchronize(ctx->aux_stream);
+    if (pin_in) (void)hipHostUnregister(const_cast<double*>(xq));
+    if (pin_out) (void)hipHostUnregister(yq);
+    (void)hipGetLastError();   // an unregister that fails (range already unpinned by the runtime) must not poison later launch checks
+    if (st != MI_OK) return st;
+    MI_HIP(ctx, e1);
+    MI_HIP(ctx, e2);
     return MI_OK;
 }
 

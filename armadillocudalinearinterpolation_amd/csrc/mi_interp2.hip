@@ -361,13 +361,43 @@ mi_status mi_interp2_f64_host(mi_ctx* ctx, const mi_grid2* g, const double* xq, 
     mi_status st = MI_OK;
     for (int s = 0; s < 3 && st == MI_OK; ++s) st = mi::ensure_scratch(ctx, s, bytes);
     if (st != MI_OK) return st;
-    MI_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], xq, bytes, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP(ctx, hipMemcpyAsync(ctx->scratch[1], yq, bytes, hipMemcpyHostToDevice, ctx->stream));
-    st = mi_interp2_f64_dev(ctx, g, (const double*)ctx->scratch[0], (const double*)ctx->scratch[1],
-                            (double*)ctx->scratch[2], nq, extrap);
+    const size_t chunk = (size_t)8 << 20;
+    if (nq <= 2 * chunk) {
+        MI_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], xq, bytes, hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(ctx, hipMemcpyAsync(ctx->scratch[1], yq, bytes, hipMemcpyHostToDevice, ctx->stream));
+        st = mi_interp2_f64_dev(ctx, g, (const double*)ctx->scratch[0], (const double*)ctx->scratch[1],
+                                (double*)ctx->scratch[2], nq, extrap);
+        if (st != MI_OK) return st;
+        MI_HIP(ctx, hipMemcpyAsync(zq, ctx->scratch[2], bytes, hipMemcpyDeviceToHost, ctx->stream));
+        MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return MI_OK;
+    }
+    // chunked and pinned like mi_interp1_f64_host: the copy back of chunk k overlaps the uploads of chunk k+1
+    st = mi::ensure_aux_stream(ctx);
     if (st != MI_OK) return st;
-    MI_HIP(ctx, hipMemcpyAsync(zq, ctx->scratch[2], bytes, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const bool pin_x = hipHostRegister(const_cast<double*>(xq), bytes, hipHostRegisterDefault) == hipSuccess;
+    const bool pin_y = hipHostRegister(const_cast<double*>(yq), bytes, hipHostRegisterDefault) == hipSuccess;
+    const bool pin_z = hipHostRegister(zq, bytes, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+    double *dx = (double*)ctx->scratch[0], *dy = (double*)ctx->scratch[1], *dz = (double*)ctx->scratch[2];
+    for (size_t off = 0; off < nq; off += chunk) {
+        const size_t m = std::min(chunk, nq - off);
+        MI_HIP(ctx, hipMemcpyAsync(dx + off, xq + off, m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(ctx, hipMemcpyAsync(dy + off, yq + off, m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        st = mi_interp2_f64_dev(ctx, g, dx + off, dy + off, dz + off, m, extrap);
+        if (st != MI_OK) break;
+        MI_HIP(ctx, hipEventRecord(ctx->aux_event, ctx->stream));
+        MI_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_event, 0));
+        MI_HIP(ctx, hipMemcpyAsync(zq + off, dz + off, m * sizeof(double), hipMemcpyDeviceToHost, ctx->aux_stream));
+    }
+    hipError_t e1 = hipStreamSynchronize(ctx->stream), e2 = hipStreamSynchronize(ctx->aux_stream);
+    if (pin_x) (void)hipHostUnregister(const_cast<double*>(xq));
+    if (pin_y) (void)hipHostUnregister(const_cast<double*>(yq));
+    if (pin_z) (void)hipHostUnregister(zq);
+    (void)hipGetLastError();   // an unregister that fails (range already unpinned by the runtime) must not poison later launch checks
+    if (st != MI_OK) return st;
+    MI_HIP(ctx, e1);
+    MI_HIP(ctx, e2);
     return MI_OK;
 }
 

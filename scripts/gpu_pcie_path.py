@@ -12,4 +12,13 @@ q = oracle.splitmix_uniform(0x5EED0003, 10**8)
 g.interp_host(q[:10**6])
 for _ in range(3):
     t = time.perf_counter(); out = g.interp_host(q); dt = time.perf_counter() - t
-    print("host path 1e8 queries: %.1f ms -> %.3g points/s, %.2f GB/s of PCIe traffic" % (dt * 1e3, 1e8 / dt, 1.6 / dt))
+    print("host path 1e8 queries, fresh result array: %.1f ms -> %.3g points/s, %.2f GB/s of PCIe traffic" % (dt * 1e3, 1e8 / dt, 1.6 / dt))
+ref = out.copy()
+for _ in range(4):
+    t = time.perf_counter(); g.interp_host(q, out=out); dt = time.perf_counter() - t
+    print("host path 1e8 queries, reused result array: %.1f ms -> %.3g points/s, %.2f GB/s of PCIe traffic" % (dt * 1e3, 1e8 / dt, 1.6 / dt))
+assert np.array_equal(out, ref, equal_nan=True)
+import torch
+dq = torch.from_numpy(q).cuda()
+assert np.array_equal(g.interp(dq).cpu().numpy(), ref, equal_nan=True)
+print("chunked host path == device path")

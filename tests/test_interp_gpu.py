@@ -235,6 +235,34 @@ def test_small_table_lds_path_equals_streaming_path(mi_ctx, n, kind):
         assert np.array_equal(a[idx].cpu().numpy(), ref, equal_nan=True)
 
 
+def test_chunked_host_paths_equal_device_paths(mi_ctx):
+    """Host convenience entry points (what the arma::vec / arma::mat wrappers call) pipeline large calls in chunks of
+    8 M queries with the caller's arrays pinned for the duration of the call; results must equal the device entry
+    points, for a ragged last chunk, for a reused and an in-place result array."""
+    import armadillocudalinearinterpolation_amd as mi
+    import torch
+    nq = 2 * (8 << 20) + 12345
+    rng = np.random.default_rng(3)
+    X = np.linspace(0.0, 1.0, 50_001)
+    g1 = mi.Grid1.from_nodes(mi_ctx, X, np.sin(9 * X))
+    q = rng.random(nq) * 1.02 - 0.01
+    q[:3] = [np.nan, 0.0, 1.0]
+    dev = g1.interp(_t(q)).cpu().numpy()
+    assert _eq(g1.interp_host(q), dev)
+    buf = np.empty_like(q)
+    assert g1.interp_host(q, out=buf) is buf and _eq(buf, dev)
+    inplace = q.copy()
+    g1.interp_host(inplace, out=inplace)
+    assert _eq(inplace, dev)
+    nx, ny = 300, 200
+    Z = rng.standard_normal((ny, nx))
+    g2 = mi.Grid2.uniform(mi_ctx, 0.0, 1.0 / (nx - 1), nx, 0.0, 1.0 / (ny - 1), ny, Z)
+    yq = rng.random(nq)
+    dev2 = g2.interp(_t(q), _t(yq)).cpu().numpy()
+    assert _eq(g2.interp_host(q, yq), dev2)
+    assert _eq(g2.interp_host(q, q), g2.interp(_t(q), _t(q)).cpu().numpy())     # both coordinate arrays are one array
+
+
 def test_queries_on_nodes_and_cell_midpoints(mi_ctx):
     import armadillocudalinearinterpolation_amd as mi
     rng = np.random.default_rng(8)
