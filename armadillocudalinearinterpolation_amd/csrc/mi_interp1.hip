@@ -899,9 +899,12 @@ mi_status mi_grid1_create(mi_ctx* ctx, const double* x, const double* y, size_t 
     for (size_t i = 0; i < n; ++i)
         if (!std::isfinite(xs[i]))
             return mi::fail(ctx, MI_ERR_GRID, "mi_grid1_create: X[%zu] is not finite", i);
-    if (flags & MI_GRID_SANITISE) {
+    bool increasing = true;
+    for (size_t i = 1; i < n && increasing; ++i) increasing = xs[i - 1] < xs[i];
+    if ((flags & MI_GRID_SANITISE) && !increasing) {
         // arma::interp1 front end: unique + ascending sort of X, Y permuted
-        // alike (first occurrence of a duplicate abscissa is kept).
+        // alike (first occurrence of a duplicate abscissa is kept).  A grid that is
+        // already strictly increasing (the usual case) skips the 40 ms sort of 1e6 nodes.
         std::vector<size_t> idx(n);
         for (size_t i = 0; i < n; ++i) idx[i] = i;
         std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return xs[a] < xs[b]; });
@@ -917,7 +920,7 @@ mi_status mi_grid1_create(mi_ctx* ctx, const double* x, const double* y, size_t 
         ys.swap(y2);
         if (xs.size() < 2)
             return mi::fail(ctx, MI_ERR_GRID, "mi_grid1_create: X must have at least two unique elements");
-    } else {
+    } else if (!increasing) {
         for (size_t i = 1; i < n; ++i)
             if (!(xs[i - 1] < xs[i]))
                 return mi::fail(ctx, MI_ERR_GRID,
