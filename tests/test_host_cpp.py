@@ -38,6 +38,38 @@ def _lcg_queries(n, seed, scale, shift):
 
 
 @pytest.mark.gpu
+def test_arma_interp_bench_runs_and_its_checksum_matches_the_oracle():
+    """The C++ end-to-end timing program of the Armadillo-shaped calls (host/arma_interp_bench.cpp) at a small size:
+    the checksum it prints over every 9973rd result must equal the oracle's on the same LCG queries."""
+    _build()
+    nq, ng = 20_000_000, 50_000                          # > 16 M queries: the chunked, pinned host path
+    out = subprocess.run([os.path.join(HOST, "arma_interp_bench"), str(nq), str(ng)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    chk = float([ln for ln in out.stdout.splitlines() if ln.startswith("checksum")][0].split()[1])
+    X = np.arange(ng) / (ng - 1)
+    Y = np.sin(6.283185307179586 * X) + 0.5 * X
+    idx = np.arange(0, nq, 9973, dtype=np.uint64)
+    # LCG state after k steps by composing the affine map x -> a x + c with itself (repeated squaring)
+    a, c, s0, mask = 6364136223846793005, 1442695040888963407, 0x5EED0003, (1 << 64) - 1
+
+    def state_after(k):
+        A, C, pa, pc = 1, 0, a, c                          # (A, C): accumulated map, (pa, pc): a^(2^j) map
+        while k:
+            if k & 1:
+                A, C = (pa * A) & mask, (pa * C + pc) & mask
+            pa, pc = (pa * pa) & mask, (pa * pc + pc) & mask
+            k >>= 1
+        return (A * s0 + C) & mask
+
+    xs = np.array([(state_after(int(i) + 1) >> 11) * 2.0 ** -53 for i in idx])
+    ref = oracle.interp1_bracket(X, Y, xs)
+    acc = 0.0
+    for v in ref:                                          # same summation order as the C++ loop
+        acc += v
+    assert chk == acc
+
+
+@pytest.mark.gpu
 def test_arma_wrappers_match_oracle(tmp_path):
     _build()
     out = subprocess.run([os.path.join(HOST, "arma_wrappers_test"), str(tmp_path)], capture_output=True, text=True)
