@@ -1,15 +1,16 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats + separate PMC passes for bench.py.
-# Usage: scripts/profile_bench.sh <round-tag>      outputs under gpurun_out/prof_<tag>/
+# Usage: scripts/profile_bench.sh <round-tag> [random|sorted|uniform]      outputs under gpurun_out/prof_<tag>/
 # The python program itself follows `--` (no env/bash hop: the profiler preloads into the process).
 set -u
 TAG=${1:-r01}
+QUERIES=${2:-random}        # random | sorted | uniform (bench.py --queries)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$REPO"
-ARGS="bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra"
+ARGS="bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --queries $QUERIES"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ARGS > "$OUT/stats.log" 2>&1
 echo "stats rc=$?"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 $ARGS > "$OUT/pmc_fetch.log" 2>&1
@@ -18,4 +19,4 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write
 echo "pmc write rc=$?"
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d "$OUT/pmc_tcc" -- python3 $ARGS > "$OUT/pmc_tcc.log" 2>&1
 echo "pmc tcc rc=$?"
-python3 scripts/parse_rocprof.py "$OUT" "$TAG"
+python3 scripts/parse_rocprof.py "$OUT" "$TAG" "$QUERIES"
