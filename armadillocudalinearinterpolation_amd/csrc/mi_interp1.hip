@@ -74,6 +74,12 @@ struct mi_grid1 {
     G1Dev d;
 };
 
+#ifndef MI_INTERP1_COOP
+#define MI_INTERP1_COOP 0   // wavefront reuse of shared nodes through __shfl (mode 3, ordered queries): implemented,
+                            // bit-exact, and slower than the three gathers it replaces (0.304 -> 0.366 ms per 1e8 sorted
+                            // queries on the jittered 1e6-node grid): off.  See eval_batch_from.
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -181,8 +187,45 @@ __device__ __forceinline__ void eval_batch_from(const G1Dev& g, const double (&q
             const int i = (int)((qs[k] - g.gorg) * g.scale);
             l[k] = min(max(i, 0), g.n - 1);
         }
+#if MI_INTERP1_COOP
+        // Wavefront reuse of shared abscissae (ordered queries, streaming kernel): when every lane's guess lies within
+        // +-30 nodes of lane 0's, the wave loads one 64-node window with a single coalesced gather (lane j: node
+        // base + j) and each lane picks its nodes out of the other lanes' registers with __shfl (ds_bpermute) --
+        // 1 + 8 cross-lane reads instead of three 16-B gathers per query.  Otherwise: the three gathers.
+        // Measured (scripts/gpu_interp_timing.py, -DMI_INTERP1_COOP=1): 21 % SLOWER -- lanes that share a line are
+        // already merged by the texture path, and eight ds_bpermute plus their waits cost more than what is left.
+        bool coop[NQ];
+        if constexpr (WIN && !LDSY) {
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const int ref = __builtin_amdgcn_readfirstlane(l[k]);
+                coop[k] = __ballot(1) == ~0ull && __all(abs(l[k] - ref) <= 30) != 0;   // the window needs all 64 lanes
+                if (coop[k]) {
+                    const int base = ref - 31;                                   // window [ref-31, ref+32]
+                    const int lane = (int)(threadIdx.x & 63u);
+                    const d2 mine = load_node<false>(ytab, min(max(base + lane, 0), g.n));
+                    const int r = l[k] - base;                                   // 1 .. 61
+                    n0[k].x = __shfl(mine.x, r, 64);
+                    n0[k].y = __shfl(mine.y, r, 64);
+                    const bool down = qs[k] < n0[k].x;
+                    const int ro = down ? r - 1 : r + 1;
+                    const double ox = __shfl(mine.x, ro, 64), oy = __shfl(mine.y, ro, 64);
+                    nm[k].x = ox; nm[k].y = oy;
+                    n1[k].x = ox; n1[k].y = oy;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) coop[k] = false;
+        }
+#else
+        bool coop[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) coop[k] = false;
+#endif
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
+            if (coop[k]) continue;
             if constexpr (WIN) nm[k] = load_node<LDSY>(ytab, max(l[k] - 1, 0));
             n0[k] = load_node<LDSY>(ytab, l[k]);
             n1[k] = load_node<LDSY>(ytab, l[k] + 1);        // index n is the padding node
