@@ -60,3 +60,20 @@ def test_product_never_imports_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert not re.search(r'#include\s*[<"][^>"]*oracle', src), f
                 assert "liboracle" not in src, f
+
+
+def test_public_header_is_plain_c99(tmp_path):
+    """include/mi355_interp.h is what a cgo / JNI / ctypes binding includes: it must compile as C99 with -pedantic,
+    and a C program must link against the library using only that header."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "c_abi.c"
+    src.write_text('#include "mi355_interp.h"\n'
+                   "int main(void) { mi_edm_params p; mi_edm_default_params(&p);\n"
+                   "  return (p.n_spikes == 3u && mi_abi_version() == MI355_INTERP_ABI_VERSION) ? 0 : 1; }\n")
+    exe = tmp_path / "c_abi"
+    lib_dir = os.path.join(root, "armadillocudalinearinterpolation_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
+           "-o", str(exe), "-L", lib_dir, "-lmi355interp", "-Wl,-rpath," + lib_dir]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
