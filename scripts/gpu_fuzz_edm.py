@@ -11,11 +11,10 @@ import numpy as np
 import oracle
 
 
-def main():
+def run(budget, seed, ctx=None):
     import armadillocudalinearinterpolation_amd as mi
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    ctx = mi.Context(0)
+    rng = np.random.default_rng(seed)
+    ctx = ctx or mi.Context(0)
     t0, cases, accepted = time.time(), 0, 0
     while time.time() - t0 < budget:
         S = int(rng.choice([1, 2, 3, 3, 3, 4, 5]))
@@ -37,12 +36,17 @@ def main():
         bad = [k for k in ("seed_ind", "w", "v", "s", "t0", "i0", "t1", "i1", "accept", "restricted") if not np.array_equal(dbg[k], d[k], equal_nan=True)]
         if bad or partial[-1] != d["sums"][-1] or not np.allclose(f, fo, rtol=0, atol=3e-7, equal_nan=True):
             print("MISMATCH", bad, kw, Z, f, fo, flush=True)
-            sys.exit(1)
+            raise AssertionError("differential fuzz mismatch (details printed above)")
         accepted += int(d["sums"][-1] > 0)
         cases += 1
         edm.close()
     os.environ.pop("MI_EDM_WAVES_PER_REALISATION", None)
     print("edm fuzz ok: %d cases in %.0f s (%d with accepted realisations)" % (cases, time.time() - t0, accepted), flush=True)
+    return {"cases": cases, "accepted": accepted}
+
+
+def main():
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 
 
 if __name__ == "__main__":

@@ -31,12 +31,10 @@ def grid_family(rng, kind, n):
     raise ValueError(kind)
 
 
-def main():
+def run(budget, seed, ctx=None):
     import armadillocudalinearinterpolation_amd as mi
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
-    ctx = mi.Context(0)
+    ctx = ctx or mi.Context(0)
     t0, cases, modes = time.time(), 0, {}
     kinds = ["linspace", "arange", "jitter", "wide_jitter", "power", "cumsum", "stretched"]
     sizes = [2, 3, 7, 64, 1000, 4095, 8191, 8192, 16383, 16384, 40000, 700000, 1200000]
@@ -76,14 +74,19 @@ def main():
                 first = out
                 if not np.array_equal(out[torch.from_numpy(sel).cuda()].cpu().numpy(), ref, equal_nan=True):
                     print("MISMATCH vs oracle", kind, n, nq, mode, style, hint, flush=True)
-                    sys.exit(1)
+                    raise AssertionError("differential fuzz mismatch (details printed above)")
             elif not torch.equal(out.view(torch.int64), first.view(torch.int64)):
                 print("MISMATCH between hints", kind, n, nq, mode, style, hint, flush=True)
-                sys.exit(1)
+                raise AssertionError("differential fuzz mismatch (details printed above)")
         ctx.set_query_order(0)
         cases += 1
         del g
     print("fuzz ok: %d cases in %.0f s, table modes seen %s" % (cases, time.time() - t0, dict(sorted(modes.items()))), flush=True)
+    return {"cases": cases, "modes": modes}
+
+
+def main():
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 
 
 if __name__ == "__main__":

@@ -22,11 +22,10 @@ def axis(rng, n):
     return np.unique((i / max(n - 1, 1)) ** rng.uniform(1.5, 3.0) * rng.uniform(1, 9))
 
 
-def main():
+def run(budget, seed, ctx=None):
     import armadillocudalinearinterpolation_amd as mi
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    ctx = mi.Context(0)
+    rng = np.random.default_rng(seed)
+    ctx = ctx or mi.Context(0)
     t0, cases = time.time(), 0
     while time.time() - t0 < budget:
         nx, ny = (int(rng.choice([2, 3, 17, 64, 255, 700])) for _ in range(2))
@@ -61,10 +60,15 @@ def main():
         if not np.array_equal(out, ref, equal_nan=True):
             bad = np.flatnonzero(~((out == ref) | (np.isnan(out) & np.isnan(ref))))
             print("MISMATCH", uniform, compact, nx, ny, nq, bad[:5], out[bad[:5]], ref[bad[:5]], flush=True)
-            sys.exit(1)
+            raise AssertionError("differential fuzz mismatch (details printed above)")
         cases += 1
         del g
     print("interp2 fuzz ok: %d cases in %.0f s" % (cases, time.time() - t0), flush=True)
+    return {"cases": cases}
+
+
+def main():
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 
 
 if __name__ == "__main__":
