@@ -51,6 +51,7 @@ SIGNATURES = {
     "mi_ctx_create": (_i32, [_i32, _pp]),
     "mi_ctx_destroy": (_i32, [_vp]),
     "mi_ctx_set_stream": (_i32, [_vp, _vp]),
+    "mi_ctx_own_stream": (_i32, [_vp]),
     "mi_ctx_synchronize": (_i32, [_vp]),
     "mi_ctx_set_query_order": (_i32, [_vp, _i32]),
     "mi_ctx_device_info": (_i32, [_vp, C.c_char_p, _sz, C.POINTER(_i32), C.POINTER(_sz)]),
@@ -81,6 +82,8 @@ SIGNATURES = {
     "mi_edm_destroy": (_i32, [_vp]),
     "mi_edm_set_params": (_i32, [_vp, C.POINTER(EdmParams)]),
     "mi_edm_compute_f": (_i32, [_vp, _vp, _vp, _vp]),
+    "mi_edm_compute_f_begin": (_i32, [_vp, _vp]),
+    "mi_edm_compute_f_end": (_i32, [_vp, _vp, _vp]),
     "mi_edm_residual_from_sums": (_i32, [C.POINTER(EdmParams), _vp, _vp, _vp]),
     "mi_edm_debug_read": (_i32, [_vp] + [_vp] * 10),
     "mi_edm_last_timings": (_i32, [_vp, C.POINTER(_f32 * 4)]),

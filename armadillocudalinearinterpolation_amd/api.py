@@ -61,6 +61,10 @@ class Context:
     def set_stream(self, raw_stream):
         check(self._L.mi_ctx_set_stream(self._h, C.c_void_p(raw_stream)), self._h)
 
+    def own_stream(self):
+        """Give this context a non-blocking stream of its own (work of several contexts can then overlap)."""
+        check(self._L.mi_ctx_own_stream(self._h), self._h)
+
     def synchronize(self):
         check(self._L.mi_ctx_synchronize(self._h), self._h)
 
@@ -386,6 +390,51 @@ class EventDrivenMap:
               self._ctx._h)
         return (f, partial) if want_partial else f
 
+    def begin(self, Z):
+        """Enqueue one evaluation and return at once (mi_edm_compute_f_begin); collect it with end()."""
+        Z = _np64(Z)
+        if Z.size != int(self.params.n_spikes):
+            raise ValueError("Z must have n_spikes=%d elements" % int(self.params.n_spikes))
+        check(self._L.mi_edm_compute_f_begin(self._h, _ptr(Z)), self._ctx._h)
+
+    def end(self, want_partial=False):
+        S = int(self.params.n_spikes)
+        f = np.empty(S, dtype=np.float64)
+        partial = np.empty(S + 1, dtype=np.float64) if want_partial else None
+        check(self._L.mi_edm_compute_f_end(self._h, _ptr(f), _ptr(partial) if want_partial else None), self._ctx._h)
+        return (f, partial) if want_partial else f
+
+    def ComputeFBatch(self, Zs, want_partial=False):
+        """Several independent evaluations at once (the columns of a finite-difference Jacobian): every
+        evaluation runs on a replica of this problem with a context and stream of its own, all are enqueued before
+        any is waited for, so they overlap on the device.  Returns F[b] (and partial[b]) in the order of Zs; each
+        equals what ComputeF(Zs[b]) returns."""
+        Zs = [np.asarray(z, dtype=np.float64) for z in Zs]
+        reps = getattr(self, "_replicas", None)
+        if reps is None:
+            reps = self._replicas = []
+        while len(reps) < len(Zs):
+            ctx = Context(self._ctx.device, stream=None)
+            ctx.own_stream()
+            h = C.c_void_p()
+            par = EdmParams()
+            C.memmove(C.byref(par), C.byref(self.params), C.sizeof(EdmParams))
+            check(self._L.mi_edm_create(ctx._h, C.byref(par), C.byref(h)), ctx._h)
+            rep = EventDrivenMap.__new__(EventDrivenMap)
+            rep._ctx, rep._L, rep.params, rep._h = ctx, self._L, par, h
+            reps.append(rep)
+        mine = bytes(self.params)
+        for rep in reps[:len(Zs)]:
+            if bytes(rep.params) != mine:                      # a setter ran on the parent since the last batch
+                C.memmove(C.byref(rep.params), C.byref(self.params), C.sizeof(EdmParams))
+                rep._push()
+        for rep, z in zip(reps, Zs):
+            rep.begin(z)
+        out = [rep.end(want_partial) for rep in reps[:len(Zs)]]
+        if want_partial:
+            return np.stack([o[0] for o in out]), np.stack([o[1] for o in out])
+        return np.stack(out)
+
     def residual_from_sums(self, Z, sums_and_count):
         Z, sc = _np64(Z), _np64(sums_and_count)
         f = np.empty(int(self.params.n_spikes), dtype=np.float64)
@@ -412,6 +461,9 @@ class EventDrivenMap:
         return {"lift_ms": ms[0], "evolve_ms": ms[1], "restrict_mean_ms": ms[2], "total_ms": ms[3]}
 
     def close(self):
+        for rep in getattr(self, "_replicas", None) or []:
+            rep.close()
+        self._replicas = []
         if getattr(self, "_h", None):
             self._L.mi_edm_destroy(self._h)
             self._h = None

@@ -32,6 +32,7 @@ struct mi_ctx {
     // reads whatever is there at the next call and uses it only to PREDICT which kernel to launch -- either kernel
     // is correct on any input.  -1 = no verdict yet (both kernels are launched, gated on the device-side flag).
     // host-convenience entry points overlap H2D, kernel and D2H of consecutive chunks: the copy back runs here
+    hipStream_t owned_stream = nullptr;  // mi_ctx_own_stream
     hipStream_t aux_stream = nullptr;   // created on first use
     hipEvent_t aux_event = nullptr;
     int* probe_host = nullptr;       // host view

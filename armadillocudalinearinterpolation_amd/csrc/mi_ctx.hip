@@ -119,6 +119,7 @@ mi_status mi_ctx_destroy(mi_ctx* ctx)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->reduce_ws) (void)hipFree(ctx->reduce_ws);
     (void)hipStreamSynchronize(ctx->stream);   // a probe in flight may still write its mailbox
+    if (ctx->owned_stream) (void)hipStreamDestroy(ctx->owned_stream);
     if (ctx->aux_event) (void)hipEventDestroy(ctx->aux_event);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->probe_host) (void)hipHostFree(ctx->probe_host);
@@ -130,6 +131,15 @@ mi_status mi_ctx_set_stream(mi_ctx* ctx, void* stream)
 {
     MI_REQUIRE(ctx, ctx != nullptr, "mi_ctx_set_stream: ctx is NULL");
     ctx->stream = (hipStream_t)stream;
+    return MI_OK;
+}
+
+mi_status mi_ctx_own_stream(mi_ctx* ctx)
+{
+    MI_REQUIRE(ctx, ctx != nullptr, "mi_ctx_own_stream: ctx is NULL");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->owned_stream) MI_HIP(ctx, hipStreamCreateWithFlags(&ctx->owned_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->owned_stream;
     return MI_OK;
 }
 

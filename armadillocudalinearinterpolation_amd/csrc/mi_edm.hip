@@ -510,6 +510,8 @@ struct mi_edm {
     size_t alloc_real = 0;
     bool w_valid = false;
     bool have_run = false;
+    bool pending = false;              // mi_edm_compute_f_begin has enqueued an evaluation, _end has not collected it
+    double pending_U0[kMaxSpikes + 1] = {0};
     uint16_t seed_ind[kMaxSpikes] = {0};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};
@@ -714,8 +716,7 @@ mi_status run_pipeline(mi_edm* e, const SpikeSeeds& sd)
     if (st != MI_OK) return st;
     MI_HIP(ctx, hipEventRecord(e->ev[3], ctx->stream));
     MI_HIP(ctx, hipMemcpyAsync(e->h_result, e->d_result, kResultBytes, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return MI_OK;
+    return MI_OK;   // nothing waited for: mi_edm_compute_f_end synchronises
 }
 
 }  // namespace
@@ -798,6 +799,7 @@ mi_status mi_edm_set_params(mi_edm* e, const mi_edm_params* p)
     const bool w_same = e->w_valid && p->n_grid == e->p.n_grid && p->L == e->p.L && p->a1 == e->p.a1 &&
                         p->a2 == e->p.a2 && p->b1 == e->p.b1 && p->b2 == e->p.b2 && p->math_mode == e->p.math_mode;
     MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    e->pending = false;   // an uncollected evaluation is abandoned
     e->p = *p;
     fill_model(e->p, &e->M);
     e->w_valid = w_same;
@@ -805,15 +807,16 @@ mi_status mi_edm_set_params(mi_edm* e, const mi_edm_params* p)
     return ensure_buffers(e);
 }
 
-mi_status mi_edm_compute_f(mi_edm* e, const double* z, double* f, double* partial)
+mi_status mi_edm_compute_f_begin(mi_edm* e, const double* z)
 {
-    MI_REQUIRE(nullptr, e != nullptr, "mi_edm_compute_f: handle is NULL");
+    MI_REQUIRE(nullptr, e != nullptr, "mi_edm_compute_f_begin: handle is NULL");
     mi_ctx* ctx = e->ctx;
-    MI_REQUIRE(ctx, z && f, "mi_edm_compute_f: NULL vector");
+    MI_REQUIRE(ctx, z != nullptr, "mi_edm_compute_f_begin: NULL vector");
+    MI_REQUIRE(ctx, !e->pending, "mi_edm_compute_f_begin: the previous evaluation has not been collected (call mi_edm_compute_f_end)");
     MI_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t S = e->p.n_spikes;
     // ZtoU (EventDrivenMap.cu:388-396) and the fp64 -> fp32 cast of :172
-    double U0[kMaxSpikes + 1];
+    double* U0 = e->pending_U0;
     U0[0] = z[0];
     U0[1] = 0.0;
     for (uint32_t i = 2; i <= S; ++i) U0[i] = z[i - 1];
@@ -824,7 +827,22 @@ mi_status mi_edm_compute_f(mi_edm* e, const double* z, double* f, double* partia
     for (uint32_t m = 0; m < S; ++m) sd.ind[m] = e->seed_ind[m];
     mi_status st = (e->p.math_mode == MI_EDM_MATH_FAST) ? run_pipeline<1>(e, sd) : run_pipeline<0>(e, sd);
     if (st != MI_OK) return st;
+    e->pending = true;
+    return MI_OK;
+}
+
+mi_status mi_edm_compute_f_end(mi_edm* e, double* f, double* partial)
+{
+    MI_REQUIRE(nullptr, e != nullptr, "mi_edm_compute_f_end: handle is NULL");
+    mi_ctx* ctx = e->ctx;
+    MI_REQUIRE(ctx, f != nullptr, "mi_edm_compute_f_end: NULL vector");
+    MI_REQUIRE(ctx, e->pending, "mi_edm_compute_f_end: no evaluation is in flight (call mi_edm_compute_f_begin)");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    e->pending = false;
+    MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
     e->have_run = true;
+    const uint32_t S = e->p.n_spikes;
+    const double* U0 = e->pending_U0;
     for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&e->last_ms[i], e->ev[i], e->ev[i + 1]);
     (void)hipEventElapsedTime(&e->last_ms[3], e->ev[0], e->ev[3]);
     const float* mean = (const float*)e->h_result;
@@ -837,6 +855,15 @@ mi_status mi_edm_compute_f(mi_edm* e, const double* z, double* f, double* partia
         partial[S] = (double)count;
     }
     return MI_OK;
+}
+
+mi_status mi_edm_compute_f(mi_edm* e, const double* z, double* f, double* partial)
+{
+    MI_REQUIRE(nullptr, e != nullptr, "mi_edm_compute_f: handle is NULL");
+    MI_REQUIRE(e->ctx, z && f, "mi_edm_compute_f: NULL vector");
+    mi_status st = mi_edm_compute_f_begin(e, z);
+    if (st != MI_OK) return st;
+    return mi_edm_compute_f_end(e, f, partial);
 }
 
 mi_status mi_edm_residual_from_sums(const mi_edm_params* p, const double* z, const double* sc, double* f)

@@ -2,6 +2,7 @@
 
 #include <cassert>
 #include <chrono>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -36,7 +37,7 @@ std::vector<float> as_float(const std::vector<T>& v)
 
 }  // namespace
 
-EventDrivenMap::EventDrivenMap(const arma::vec* pParameters, unsigned int noReal, int device) : ctx_(nullptr), edm_(nullptr)
+EventDrivenMap::EventDrivenMap(const arma::vec* pParameters, unsigned int noReal, int device) : ctx_(nullptr), edm_(nullptr), device_(device)
 {
     assert(pParameters && pParameters->n_elem >= 1);
     must(mi_ctx_create(device, &ctx_), nullptr, "mi_ctx_create");
@@ -52,6 +53,10 @@ EventDrivenMap::EventDrivenMap(const arma::vec* pParameters, unsigned int noReal
 
 EventDrivenMap::~EventDrivenMap()
 {
+    for (Replica& r : replicas_) {
+        mi_edm_destroy(r.edm);
+        mi_ctx_destroy(r.ctx);
+    }
     mi_edm_destroy(edm_);
     mi_ctx_destroy(ctx_);
 }
@@ -65,6 +70,45 @@ void EventDrivenMap::ComputeF(const arma::vec& u, arma::vec& f)
     partial_.set_size(p_.n_spikes + 1);
     must(mi_edm_compute_f(edm_, u.memptr(), f.memptr(), partial_.memptr()), ctx_, "mi_edm_compute_f");
     if (debug_) Dump();
+}
+
+void EventDrivenMap::ComputeFBatch(const arma::mat& U, arma::mat& F)
+{
+    const arma::uword S = p_.n_spikes, B = U.n_cols;
+    assert(U.n_rows == S);
+    F.set_size(S, B);
+    if (debug_) {                                       // the Save* dumps follow every single evaluation: keep them
+        arma::vec u(S), f;
+        for (arma::uword j = 0; j < B; ++j) {
+            for (arma::uword i = 0; i < S; ++i) u(i) = U(i, j);
+            ComputeF(u, f);
+            for (arma::uword i = 0; i < S; ++i) F(i, j) = f(i);
+        }
+        return;
+    }
+    while (replicas_.size() < B) {                      // one context with a stream of its own per evaluation in flight
+        Replica r;
+        r.p = p_;
+        must(mi_ctx_create(device_, &r.ctx), nullptr, "mi_ctx_create");
+        must(mi_ctx_own_stream(r.ctx), r.ctx, "mi_ctx_own_stream");
+        must(mi_edm_create(r.ctx, &r.p, &r.edm), r.ctx, "mi_edm_create");
+        replicas_.push_back(r);
+    }
+    std::vector<double> z(S), f(S);
+    for (arma::uword j = 0; j < B; ++j) {
+        Replica& r = replicas_[j];
+        if (std::memcmp(&r.p, &p_, sizeof(p_)) != 0) {   // a setter ran since the last batch
+            r.p = p_;
+            must(mi_edm_set_params(r.edm, &r.p), r.ctx, "mi_edm_set_params");
+        }
+        for (arma::uword i = 0; i < S; ++i) z[i] = U(i, j);
+        must(mi_edm_compute_f_begin(r.edm, z.data()), r.ctx, "mi_edm_compute_f_begin");
+    }
+    for (arma::uword j = 0; j < B; ++j) {
+        Replica& r = replicas_[j];
+        must(mi_edm_compute_f_end(r.edm, f.data(), nullptr), r.ctx, "mi_edm_compute_f_end");
+        for (arma::uword i = 0; i < S; ++i) F(i, j) = f[i];
+    }
 }
 
 void EventDrivenMap::ResidualFromSums(const arma::vec& u, const arma::vec& sums_and_count, arma::vec& f) const

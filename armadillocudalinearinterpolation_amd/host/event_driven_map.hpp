@@ -6,11 +6,12 @@
 // parameter block and the optional debug dumps.
 #pragma once
 #include <string>
+#include <vector>
 
 #include "mi355_interp.h"
 #include "nonlinear_problem.hpp"
 
-class EventDrivenMap : public AbstractNonlinearProblem {
+class EventDrivenMap : public AbstractNonlinearProblem, public AbstractBatchedNonlinearProblem {
   public:
     EventDrivenMap(const arma::vec* pParameters, unsigned int noReal, int device = 0);
     ~EventDrivenMap() override;
@@ -19,6 +20,8 @@ class EventDrivenMap : public AbstractNonlinearProblem {
 
     // residual f(Z), Z = (c, Z1, .., Z_{S-1})   (EventDrivenMap.cu:154-240)
     void ComputeF(const arma::vec& u, arma::vec& f) override;
+    // independent evaluations overlapped on the device: one replica (context + stream + buffers) per column
+    void ComputeFBatch(const arma::mat& U, arma::mat& F) override;
 
     // setters of EventDrivenMap.hpp:27-51 (each echoes to stdout like the reference)
     void SetTimeHorizon(const float T);
@@ -50,6 +53,9 @@ class EventDrivenMap : public AbstractNonlinearProblem {
     mi_ctx* ctx_;
     mi_edm* edm_;
     mi_edm_params p_;
+    struct Replica { mi_ctx* ctx; mi_edm* edm; mi_edm_params p; };
+    std::vector<Replica> replicas_;
+    int device_ = 0;
     arma::vec partial_;
     bool debug_ = false, quiet_ = false;
     std::string debug_dir_ = ".";

@@ -55,6 +55,19 @@ void NewtonSolver::ForwardDifferenceJacobian(const arma::vec& u, const arma::vec
     const arma::uword n = guess_->n_rows;
     const double eps = pars_->finiteDifferenceEpsilon;
     const double inv_eps = std::pow(eps, -1);
+    if (auto* batched = dynamic_cast<AbstractBatchedNonlinearProblem*>(problem_)) {
+        // the n perturbed residuals are independent: hand them over together (same values as the loop below)
+        arma::mat U(n, n), F;
+        for (arma::uword i = 0; i < n; ++i) {
+            for (arma::uword r = 0; r < n; ++r) U(r, i) = u(r);
+            U(i, i) += eps;
+        }
+        batched->ComputeFBatch(U, F);
+        last_evaluations_ += (int)n;
+        for (arma::uword i = 0; i < n; ++i)
+            for (arma::uword r = 0; r < n; ++r) J(r, i) = (F(r, i) - f(r)) * inv_eps;
+        return;
+    }
     arma::vec du(u), df(n);
     for (arma::uword i = 0; i < n; ++i) {
         if (i > 0) du(i - 1) = u(i - 1);     // undo the previous column's perturbation

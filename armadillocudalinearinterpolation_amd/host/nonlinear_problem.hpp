@@ -21,3 +21,12 @@ class AbstractNonlinearProblemJacobian {
     virtual ~AbstractNonlinearProblemJacobian() {}
     virtual void ComputeDFDU(const arma::vec& u, arma::mat& dfdu) = 0;
 };
+
+// optional (not in the reference): several independent residual evaluations at once -- the columns of a
+// finite-difference Jacobian.  Column j of F is what ComputeF(column j of U) returns.  A problem that implements it
+// may overlap the evaluations on the device; NewtonSolver uses it when the problem offers it.
+class AbstractBatchedNonlinearProblem {
+  public:
+    virtual ~AbstractBatchedNonlinearProblem() {}
+    virtual void ComputeFBatch(const arma::mat& U, arma::mat& F) = 0;
+};

@@ -22,6 +22,7 @@ class NewtonSolver:
     def __init__(self, problem, initial_guess, pars, jacobian=None, printer=print):
         self.problem, self.guess, self.pars, self.jacobian, self._print = problem, initial_guess, pars, jacobian, printer
         self.evaluations = 0
+        self.concurrent_columns = True   # use problem.ComputeFBatch for the finite-difference columns when it exists
 
     def _F(self, u):
         self.evaluations += 1
@@ -31,6 +32,20 @@ class NewtonSolver:
         n, eps = u.size, self.pars.finiteDifferenceEpsilon
         inv_eps = eps ** -1
         J = np.empty((n, n))
+        batch = getattr(self.problem, "ComputeFBatch", None)
+        if batch is not None and self.concurrent_columns:
+            # the n perturbed residuals are independent: enqueue them all, then collect (same values, same order of
+            # floating-point operations per column as the loop below)
+            pert = []
+            for i in range(n):
+                du = u.copy()
+                du[i] += eps
+                pert.append(du)
+            F = np.asarray(batch(pert), dtype=np.float64)
+            self.evaluations += n
+            for i in range(n):
+                J[:, i] = (F[i] - f) * inv_eps
+            return J
         du = u.copy()
         for i in range(n):
             if i > 0:

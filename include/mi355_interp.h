@@ -68,6 +68,9 @@ mi_status mi_ctx_create(int device, mi_ctx** out);
 mi_status mi_ctx_destroy(mi_ctx* ctx);
 /* stream: a hipStream_t (NULL = the device's default stream). */
 mi_status mi_ctx_set_stream(mi_ctx* ctx, void* stream);
+/* give the context a non-blocking stream of its own (created here, destroyed with the context): lets work of
+ * several contexts on one device overlap without the caller touching the HIP API */
+mi_status mi_ctx_own_stream(mi_ctx* ctx);
 mi_status mi_ctx_synchronize(mi_ctx* ctx);
 const char* mi_last_error(const mi_ctx* ctx);
 int mi_abi_version(void);
@@ -236,6 +239,13 @@ mi_status mi_edm_set_params(mi_edm* e, const mi_edm_params* p);
  * count so that a caller sharding realisations over GPUs can all-reduce them;
  * when partial is non-NULL f is still the single-device residual. */
 mi_status mi_edm_compute_f(mi_edm* e, const double* z, double* f, double* partial);
+/* The same in two halves: _begin enqueues the whole evaluation on the context's stream and returns at once,
+ * _end waits for it and forms f (and partial).  Independent evaluations -- the columns of NewtonSolver's
+ * finite-difference Jacobian (NewtonSolver.cpp:178-197) -- can then overlap on the device: one mi_ctx (with its own
+ * stream) and one mi_edm per evaluation in flight, _begin on all of them, _end on all of them.  One evaluation per
+ * handle at a time. */
+mi_status mi_edm_compute_f_begin(mi_edm* e, const double* z);
+mi_status mi_edm_compute_f_end(mi_edm* e, double* f, double* partial);
 /* f from all-reduced partial sums (host arithmetic of EventDrivenMap.cu:237-239) */
 mi_status mi_edm_residual_from_sums(const mi_edm_params* p, const double* z, const double* sums_and_count,
                                     double* f);

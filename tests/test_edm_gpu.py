@@ -194,6 +194,39 @@ def test_dedup_identical_is_bit_identical_to_full_evolution(mi_ctx):
     assert np.array_equal(d_full["t0"], d_dd["t0"]) and not np.all(d_dd["t0"].reshape(3, 3000) == d_dd["t0"].reshape(3, 3000)[:, :1])
 
 
+def test_concurrent_evaluations_equal_sequential_ones(mi_ctx):
+    """mi_edm_compute_f_begin/_end on replicas with streams of their own (ComputeFBatch: the columns of the
+    finite-difference Jacobian evaluated together) give, column by column, exactly what ComputeF gives; setters on the
+    parent reach the replicas; the Newton iterates with and without concurrent columns are identical."""
+    import armadillocudalinearinterpolation_amd as mi
+    from armadillocudalinearinterpolation_amd import newton
+    edm = mi.EventDrivenMap(mi_ctx, [13.0589], 700, n_grid=512)
+    Zs = [np.array(Z_DRIVER) + d for d in ([0, 0, 0], [1e-2, 0, 0], [0, 1e-2, 0], [0, 0, 1e-2], [-5e-3, 2e-3, 0])]
+    seq = np.stack([edm.ComputeF(z) for z in Zs])
+    assert np.array_equal(edm.ComputeFBatch(Zs), seq)
+    F, P = edm.ComputeFBatch(Zs[:2], want_partial=True)
+    assert np.array_equal(F, seq[:2]) and P.shape == (2, 4) and np.all(P[:, -1] == P[0, -1])
+    edm.SetParameterStdDev(0.3)                          # the replicas must pick this up
+    seq2 = np.stack([edm.ComputeF(z) for z in Zs[:3]])
+    assert not np.array_equal(seq2, seq[:3])
+    assert np.array_equal(edm.ComputeFBatch(Zs[:3]), seq2)
+    with pytest.raises(mi.MiError):                      # one evaluation per handle at a time
+        edm.begin(Zs[0])
+        edm.begin(Zs[1])
+    edm.end()
+    edm.close()
+    runs = []
+    for concurrent in (True, False):
+        prob = mi.EventDrivenMap(mi_ctx, [13.0589], 300, n_grid=1024)
+        pars = newton.ParameterList(tolerance=1e-4, maxIterations=10, printOutput=False, finiteDifferenceEpsilon=1e-2)
+        solver = newton.NewtonSolver(prob, np.array(Z_DRIVER), pars)
+        solver.concurrent_columns = concurrent
+        runs.append(solver.Solve())
+        prob.close()
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1], equal_nan=True)
+    assert runs[0][2] == runs[1][2] and runs[0][3] == runs[1][3]
+
+
 def test_python_newton_on_gpu_matches_oracle_newton(mi_ctx):
     """The replicated Newton loop used for multi-GPU runs (newton.py), here on one GPU with 1024 grid points."""
     import armadillocudalinearinterpolation_amd as mi
