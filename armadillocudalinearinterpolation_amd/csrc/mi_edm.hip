@@ -778,6 +778,7 @@ mi_status mi_edm_destroy(mi_edm* e)
 {
     if (!e) return MI_OK;
     (void)hipSetDevice(e->ctx->device);
+    if (e->pending) (void)hipStreamSynchronize(e->ctx->stream);   // an evaluation begun and never collected still uses the buffers
     free_real_buffers(e);
     void* bufs[] = {e->d_v, e->d_s, e->d_w, e->d_result, e->d_one};
     for (void* b : bufs)
