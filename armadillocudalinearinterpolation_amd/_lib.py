@@ -47,6 +47,8 @@ _pp = C.POINTER(C.c_void_p)
 # the declarations in include/mi355_interp.h.
 SIGNATURES = {
     "mi_abi_version": (_i32, []),
+    "mi_debug_pinned_ranges": (_sz, []),
+    "mi_debug_sweep_timing": (_i32, [_vp, _vp]),
     "mi_last_error": (C.c_char_p, [_vp]),
     "mi_ctx_create": (_i32, [_i32, _pp]),
     "mi_ctx_destroy": (_i32, [_vp]),
@@ -77,6 +79,23 @@ SIGNATURES = {
     "mi_masked_mean_f32_dev": (_i32, [_vp, _vp, _vp, _sz, _sz, _i32, _vp, _vp, _vp]),
     "mi_restrict_mean_f32_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _sz, _sz, _i32,
                                         _vp, _vp, _vp, _vp]),
+    "mi_group_create": (_i32, [_i32, C.POINTER(_i32), _pp]),
+    "mi_group_destroy": (_i32, [_vp]),
+    "mi_group_size": (_i32, [_vp]),
+    "mi_group_ctx": (_vp, [_vp, _i32]),
+    "mi_group_synchronize": (_i32, [_vp]),
+    "mi_shard_bounds": (None, [_sz, _i32, _i32, C.POINTER(_sz), C.POINTER(_sz)]),
+    "mi_group_set_reduce": (_i32, [_vp, _i32]),
+    "mi_group_grid1_create": (_i32, [_vp, _vp, _vp, _sz, C.c_uint, _pp]),
+    "mi_group_grid1_destroy": (_i32, [_vp]),
+    "mi_group_interp1_f64_host": (_i32, [_vp, _vp, _vp, _vp, _sz, _dbl]),
+    "mi_group_interp1_f64_dev": (_i32, [_vp, _vp, _pp, _pp, _sz, _dbl, _pp]),
+    "mi_group_edm_create": (_i32, [_vp, C.POINTER(EdmParams), _pp]),
+    "mi_group_edm_destroy": (_i32, [_vp]),
+    "mi_group_edm_set_params": (_i32, [_vp, C.POINTER(EdmParams)]),
+    "mi_group_edm_compute_f": (_i32, [_vp, _vp, _vp, _vp]),
+    "mi_group_edm_shard": (_vp, [_vp, _i32]),
+    "mi_group_edm_shard_bounds": (_i32, [_vp, _i32, C.POINTER(_sz), C.POINTER(_sz)]),
     "mi_edm_default_params": (None, [C.POINTER(EdmParams)]),
     "mi_edm_create": (_i32, [_vp, C.POINTER(EdmParams), _pp]),
     "mi_edm_destroy": (_i32, [_vp]),
@@ -124,8 +143,8 @@ def load(build_if_missing=True, strict=True):
         fn.argtypes = args
     if missing and strict:
         raise RuntimeError("libmi355interp.so lacks symbols declared in mi355_interp.h: %s" % ", ".join(missing))
-    if L.mi_abi_version() != 1:
-        raise RuntimeError("libmi355interp.so ABI version %d != 1" % L.mi_abi_version())
+    if L.mi_abi_version() != 2:
+        raise RuntimeError("libmi355interp.so ABI version %d != 2" % L.mi_abi_version())
     _lib = L
     return L
 

@@ -296,7 +296,7 @@ def masked_mean(ctx, x, accept, nspikes, quirk=False, want_sums=False):
     assert x.numel() == nspikes * nreal
     mean = torch.empty(nspikes, dtype=torch.float32, device=x.device)
     count = torch.empty(1, dtype=torch.int32, device=x.device)
-    sums = torch.empty(nspikes, dtype=torch.float64, device=x.device) if want_sums else None
+    sums = torch.empty(2 * nspikes + 1, dtype=torch.float64, device=x.device) if want_sums else None   # [sums | count | x0]
     check(ctx._L.mi_masked_mean_f32_dev(ctx._h, _ptr(x), _ptr(accept), nreal, nspikes, int(bool(quirk)),
                                         _ptr(mean), _ptr(count), _ptr(sums) if want_sums else None), ctx._h)
     return (mean, count, sums) if want_sums else (mean, count)
@@ -309,7 +309,7 @@ def restrict_mean(ctx, t0, i0, t1, i1, accept, final_time, half_length, ngrid, n
     assert t0.numel() == nspikes * nreal
     mean = torch.empty(nspikes, dtype=torch.float32, device=t0.device)
     count = torch.empty(1, dtype=torch.int32, device=t0.device)
-    sums = torch.empty(nspikes, dtype=torch.float64, device=t0.device) if want_sums else None
+    sums = torch.empty(2 * nspikes + 1, dtype=torch.float64, device=t0.device) if want_sums else None   # [sums | count | x0]
     restricted = torch.empty_like(t0) if want_restricted else None
     check(ctx._L.mi_restrict_mean_f32_dev(ctx._h, _ptr(t0), _ptr(i0), _ptr(t1), _ptr(i1), _ptr(accept),
                                           float(final_time), float(half_length), int(ngrid), nreal, nspikes,
@@ -385,7 +385,7 @@ class EventDrivenMap:
         if Z.size != S:
             raise ValueError("Z must have n_spikes=%d elements" % S)
         f = np.empty(S, dtype=np.float64)
-        partial = np.empty(S + 1, dtype=np.float64) if want_partial else None
+        partial = np.empty(2 * S + 1, dtype=np.float64) if want_partial else None   # MI_EDM_PARTIAL_LEN(S)
         check(self._L.mi_edm_compute_f(self._h, _ptr(Z), _ptr(f), _ptr(partial) if want_partial else None),
               self._ctx._h)
         return (f, partial) if want_partial else f
@@ -400,7 +400,7 @@ class EventDrivenMap:
     def end(self, want_partial=False):
         S = int(self.params.n_spikes)
         f = np.empty(S, dtype=np.float64)
-        partial = np.empty(S + 1, dtype=np.float64) if want_partial else None
+        partial = np.empty(2 * S + 1, dtype=np.float64) if want_partial else None   # MI_EDM_PARTIAL_LEN(S)
         check(self._L.mi_edm_compute_f_end(self._h, _ptr(f), _ptr(partial) if want_partial else None), self._ctx._h)
         return (f, partial) if want_partial else f
 

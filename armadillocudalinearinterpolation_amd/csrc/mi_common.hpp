@@ -64,6 +64,16 @@ inline unsigned stream_grid(const mi_ctx* ctx, size_t work_items, unsigned block
 mi_status ensure_scratch(mi_ctx* ctx, int slot, size_t bytes);
 mi_status ensure_aux_stream(mi_ctx* ctx);
 
+// Page-locking of a caller's host range for the duration of one host-convenience call (asynchronous copies need it).
+// Process-wide and reference counted: two calls (two contexts, two threads) that hand over the SAME array share one
+// registration, and the range is unregistered only when the last of them has drained its streams -- an early
+// hipHostUnregister by one call would pull the pinning out from under the other's copies in flight.  A range the
+// library did not register itself (already pinned by the caller, or not pinnable) is left alone: hipMemcpyAsync then
+// takes its blocking path.  pin_host returns true when this call holds a reference it must give back with unpin_host.
+bool pin_host(const void* p, size_t bytes);
+void unpin_host(const void* p);
+size_t pinned_ranges();   // test hook (mi_debug_pinned_ranges)
+
 }  // namespace mi
 
 #define MI_HIP(ctx, call)                                                                   \

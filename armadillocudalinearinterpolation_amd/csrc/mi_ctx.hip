@@ -1,6 +1,8 @@
 // Context, error reporting and HIP-event timers of libmi355interp.so.
 #include "mi_common.hpp"
 
+#include <map>
+
 namespace mi {
 
 char* tls_error()
@@ -46,11 +48,57 @@ mi_status ensure_aux_stream(mi_ctx* ctx)
     return MI_OK;
 }
 
+namespace {
+struct PinEntry { size_t bytes; unsigned refs; };
+std::mutex g_pin_mu;
+std::map<const void*, PinEntry>& pin_table()
+{
+    static std::map<const void*, PinEntry> t;
+    return t;
+}
+}  // namespace
+
+bool pin_host(const void* p, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto& t = pin_table();
+    auto it = t.find(p);
+    if (it != t.end()) {
+        if (it->second.bytes >= bytes) { ++it->second.refs; return true; }
+        return false;   // a longer range from the same base while a shorter one is pinned: blocking copies for this call
+    }
+    const hipError_t e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }   // pinned by the caller already, or not pinnable
+    t.emplace(p, PinEntry{bytes, 1u});
+    return true;
+}
+
+void unpin_host(const void* p)
+{
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto& t = pin_table();
+    auto it = t.find(p);
+    if (it == t.end()) return;
+    if (--it->second.refs == 0) {
+        (void)hipHostUnregister(const_cast<void*>(p));
+        (void)hipGetLastError();   // an unregister that fails must not poison later launch checks
+        t.erase(it);
+    }
+}
+
+size_t pinned_ranges()
+{
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    return pin_table().size();
+}
+
 }  // namespace mi
 
 extern "C" {
 
 int mi_abi_version(void) { return MI355_INTERP_ABI_VERSION; }
+
+size_t mi_debug_pinned_ranges(void) { return mi::pinned_ranges(); }
 
 const char* mi_last_error(const mi_ctx* ctx) { return ctx ? ctx->err : mi::tls_error(); }
 
@@ -115,10 +163,14 @@ mi_status mi_ctx_destroy(mi_ctx* ctx)
 {
     if (!ctx) return MI_OK;
     (void)hipSetDevice(ctx->device);
+    // drain first: kernels in flight still use the reduction workspace (partials, order flags), the scratch slots
+    // and the probe mailbox
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->owned_stream && ctx->owned_stream != ctx->stream) (void)hipStreamSynchronize(ctx->owned_stream);
+    if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     for (int i = 0; i < 3; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->reduce_ws) (void)hipFree(ctx->reduce_ws);
-    (void)hipStreamSynchronize(ctx->stream);   // a probe in flight may still write its mailbox
     if (ctx->owned_stream) (void)hipStreamDestroy(ctx->owned_stream);
     if (ctx->aux_event) (void)hipEventDestroy(ctx->aux_event);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
@@ -188,6 +240,7 @@ mi_status mi_timer_destroy(mi_timer* t)
 mi_status mi_timer_start(mi_timer* t)
 {
     MI_REQUIRE(nullptr, t != nullptr, "mi_timer_start: timer is NULL");
+    MI_HIP(t->ctx, hipSetDevice(t->ctx->device));
     MI_HIP(t->ctx, hipEventRecord(t->start, t->ctx->stream));
     return MI_OK;
 }
@@ -195,6 +248,7 @@ mi_status mi_timer_start(mi_timer* t)
 mi_status mi_timer_stop(mi_timer* t)
 {
     MI_REQUIRE(nullptr, t != nullptr, "mi_timer_stop: timer is NULL");
+    MI_HIP(t->ctx, hipSetDevice(t->ctx->device));
     MI_HIP(t->ctx, hipEventRecord(t->stop, t->ctx->stream));
     return MI_OK;
 }

@@ -519,7 +519,7 @@ struct mi_edm {
 
 namespace {
 
-constexpr size_t kResultBytes = 8 * 4 + 8 + 8 * 8;
+constexpr size_t kResultBytes = 8 * 4 + 8 + (2 * 8 + 1) * 8;   // mean f32[8] | count u32 (+pad) | partial block f64[2*8+1]
 // evolve kernel choice by realisation count (launch_evolve): below kWgNarrow four waves per realisation (latency
 // form), else one wave per realisation (throughput form).  scripts/gpu_edm_wpr.py, N = 1024: R <= 256 4.6 -> 2.6 ms,
 // R = 1000 equal, R >= 2000 the throughput form wins (2x at 16 K); 16 waves per realisation were slower than 4
@@ -711,7 +711,10 @@ mi_status run_pipeline(mi_edm* e, const SpikeSeeds& sd)
     if (st != MI_OK) return st;
     MI_HIP(ctx, hipEventRecord(e->ev[2], ctx->stream));
     st = mi_restrict_mean_f32_dev(ctx, e->d_t0, e->d_i0, e->d_t1, e->d_i1, e->d_accept, e->p.time_horizon, e->p.L,
-                                  e->p.n_grid, e->p.n_real, e->p.n_spikes, e->p.mean_quirk, nullptr,
+                                  e->p.n_grid, e->p.n_real, e->p.n_spikes,
+                                  // realisation 0 of the WHOLE ensemble is the one the reference drops: only the shard that
+                                  // holds it applies the rule locally (the others report plain sums)
+                                  (e->p.mean_quirk != 0 && e->p.real_offset == 0) ? 1 : 0, nullptr,
                                   (float*)e->d_result, (uint32_t*)(e->d_result + 32), (double*)(e->d_result + 40));
     if (st != MI_OK) return st;
     MI_HIP(ctx, hipEventRecord(e->ev[3], ctx->stream));
@@ -738,7 +741,7 @@ void mi_edm_default_params(mi_edm_params* p)
     p->beta_stddev = 0.0f;
     p->seed = 0x5EED0005ull;
     p->math_mode = MI_EDM_MATH_EXACT;
-    p->mean_quirk = 0;
+    p->mean_quirk = 1;   // the reference's averaging, as written (EventDrivenMap.cu:800-802,:817,:822); 0 = the true mean
     p->max_events = 1u << 20;
     p->real_offset = 0;
     p->dedup_identical = 0;
@@ -851,9 +854,9 @@ mi_status mi_edm_compute_f_end(mi_edm* e, double* f, double* partial)
     const double* sums = (const double*)(e->h_result + 40);
     // host epilogue, EventDrivenMap.cu:237-239 (fp64)
     for (uint32_t m = 0; m < S; ++m) f[m] = (-U0[0] * U0[m + 1] - (double)mean[m]) + U0[0] * (double)e->p.time_horizon;
+    (void)count;
     if (partial) {
-        for (uint32_t m = 0; m < S; ++m) partial[m] = sums[m];
-        partial[S] = (double)count;
+        for (uint32_t m = 0; m < 2 * S + 1; ++m) partial[m] = sums[m];   // [sums | count | x0], MI_EDM_PARTIAL_LEN(S)
     }
     return MI_OK;
 }
@@ -878,8 +881,11 @@ mi_status mi_edm_residual_from_sums(const mi_edm_params* p, const double* z, con
     for (uint32_t i = 2; i <= S; ++i) U0[i] = z[i - 1];
     const double count = sc[S];
     for (uint32_t m = 0; m < S; ++m) {
-        // same rounding as the single-device path: fp64 sum / count, rounded to fp32 once
-        const float mean = (float)(sc[m] / count);
+        // same rule and rounding as the single-device path (mean_stage2_kernel): realisation 0 re-enters the sum only
+        // when exactly one realisation of the whole ensemble was accepted (EventDrivenMap.cu:800-802,:817), then
+        // fp64 sum / count, rounded to fp32 once
+        const double s = sc[m] + ((p->mean_quirk != 0 && count == 1.0) ? sc[S + 1 + m] : 0.0);
+        const float mean = (float)(s / count);
         f[m] = (-U0[0] * U0[m + 1] - (double)mean) + U0[0] * (double)p->time_horizon;
     }
     return MI_OK;

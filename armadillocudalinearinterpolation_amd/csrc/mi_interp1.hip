@@ -474,6 +474,9 @@ __global__ __launch_bounds__(kLdsBlock) void interp1_lds_kernel(G1Dev g, const d
 #ifndef MI_SWEEP_BLOCKS_PER_CU
 #define MI_SWEEP_BLOCKS_PER_CU 1
 #endif
+#ifndef MI_SWEEP_DYNAMIC
+#define MI_SWEEP_DYNAMIC 0   // hand the gather chunks out dynamically: measured 0.711-0.716 vs 0.707-0.716 ms static -- no gain, off
+#endif
 constexpr int kSweepThreads = MI_SWEEP_THREADS;
 constexpr int kSweepK = MI_SWEEP_K;                       // queries per lane per tile
 constexpr int kSweepTile = kSweepThreads * kSweepK;       // queries per tile (8 B of LDS each)
@@ -486,6 +489,7 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
 {
     __shared__ double sq[kSweepTile];
     __shared__ unsigned hist[kSweepBins];
+    __shared__ unsigned next_chunk;          // gather phase: chunks of 256 sorted positions handed out to the waves
     const int tid = threadIdx.x;
     if (*order_flag != 0) return;            // queries already ordered locally: the streaming kernel does the work
     // The last workgroup has the fewest tiles: it also probes the query order for the next call (one wave, while
@@ -504,6 +508,7 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
             q[2 * u + 1] = v.y;
         }
         for (int b = tid; b < kSweepBins; b += kSweepThreads) hist[b] = 0;
+        if (tid == 0) next_chunk = 0;
         __syncthreads();
         unsigned short bin[kSweepK], rank[kSweepK];
 #pragma unroll
@@ -536,6 +541,30 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
             sq[sp[u]] = q[u];
         }
         __syncthreads();
+#if MI_SWEEP_DYNAMIC
+        // The waves of a CU do not reach the end of the gather rounds together (2.4 us between the first and the last of
+        // eight, profiles/r02_sweep_pipelined_phases.log).  Handing the sorted positions out in chunks of 256 (four per
+        // lane), in order, to whichever wave is free does not shorten the phase (the memory path returns in order: the
+        // wave that issued last finishes last whatever it was given): experiment kept for reference.
+        for (;;) {
+            unsigned c = 0;
+            if ((tid & 63) == 0) c = atomicAdd(&next_chunk, 1u);
+            c = __builtin_amdgcn_readfirstlane(c);
+            if (c >= (unsigned)(kSweepTile / 256)) break;
+            double qq[4], rr[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int p = (int)c * 256 + w * 64 + (tid & 63);
+                qq[w] = sq[rev ? kSweepTile - 1 - p : p];
+            }
+            eval_batch<MODE, 4, FORMULA>(g, qq, rr, extrap);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int p = (int)c * 256 + w * 64 + (tid & 63);
+                sq[rev ? kSweepTile - 1 - p : p] = rr[w];
+            }
+        }
+#else
 #pragma unroll
         for (int u = 0; u < kSweepK; u += 4) {
             double qq[4], rr[4];
@@ -551,6 +580,7 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
                 sq[rev ? kSweepTile - 1 - p : p] = rr[w];
             }
         }
+#endif
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < kSweepK / 2; ++u) {
@@ -578,6 +608,283 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const size_t i = (size_t)tid + (size_t)(u + w) * kSweepThreads;
+                if (i < tail) to[i] = rr[w];
+            }
+        }
+    }
+}
+
+// ---- region sweep, pipelined form (round 2) ----------------------------------------------------------------
+// Same tiles, same in-LDS counting sort, same arithmetic as interp1_sweep_kernel, but the HBM streams of one tile run
+// WHILE another tile gathers.  Measured (scripts/exp_mix.hip, profiles/r02_exp_mix.log): stream loads or stores issued
+// by OTHER waves of the CU, a few wave-instructions at a time, cost the L2-hit gathers of the gathering waves about
+// 12 % -- what hurt every overlap scheme of round 1 was the burst (all CUs loading 128 KiB at the same moment) and
+// loads issued by the gathering waves themselves (vmcnt is in order within a wave).  So: one 1024-lane workgroup per
+// CU, two groups of 8 waves that swap roles tile by tile.
+//   gatherer of tile t : gather + blend rounds over the sorted LDS tile (8 rounds of 4 queries per lane), reads its
+//                        results back, stores them (no wait) and issues the loads of tile t+2 into registers (no wait)
+//   preparer of tile t+1: its queries arrived in registers during the previous step; region histogram (LDS atomics,
+//                        its own histogram), prefix, sorted positions -- all while the other group gathers -- and the
+//                        scatter into the LDS tile once the gatherer has read its results out.
+// The one LDS tile (16 384 queries, 128 KiB) is the only hand-over point; six workgroup barriers per tile, none of
+// which waits for vector memory.  Every workgroup runs the same schedule, so the chip still sweeps the table regions
+// in step (that is what keeps the gathers in L2).
+constexpr int kPipeGroup = 512;                          // lanes per group = kSweepTile / kSweepK
+constexpr int kPipeThreads = 2 * kPipeGroup;
+static_assert(kSweepTile == kPipeGroup * kSweepK, "one group covers a tile with kSweepK queries per lane");
+
+// test hook (mi_debug_sweep_timing): when set, lane 0 of each group accumulates wall_clock64 ticks (100 MHz) per role and
+// schedule interval into [workgroup][group][role: 0 gather, 1 prepare][interval 0..5]
+__device__ unsigned long long* g_pipe_timing = nullptr;
+
+__device__ __forceinline__ void pipe_barrier()
+{
+    // LDS traffic of this wave done, then the workgroup barrier; vector memory stays in flight across it
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// two gather rounds (2 x 4 queries per lane) starting at sorted position first + lane, walking by `stride` (+512 sweeping
+// the regions upwards, -512 downwards); kept as a rolled loop: the unrolled form of all 8 rounds x 2 roles x 2 groups
+// overwhelms the register allocator at the 128 registers a 1024-lane workgroup leaves per lane
+template <int MODE, int FORMULA>
+__device__ __forceinline__ void pipe_gather_rounds(const G1Dev& g, double* sq, int first, int stride, double extrap)
+{
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+        double qq[4], rr[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) qq[w] = sq[first + (4 * r + w) * stride];
+        eval_batch<MODE, 4, FORMULA>(g, qq, rr, extrap);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sq[first + (4 * r + w) * stride] = rr[w];
+    }
+}
+
+// SCHED 0: the gatherer issues all sixteen loads of its next tile right behind its result stores (one burst per tile);
+// SCHED 1: the preparer issues them itself at the start of its step, in two halves; SCHED 2: one vector at a time,
+// spread over the first ~10 us of the other group's gather rounds.
+// Three workgroup barriers per tile: after the gather rounds, after the read-back, after the scatter.  The preparing
+// group orders its own histogram -> prefix -> positions passes with a counter in LDS that only its 8 waves touch, so
+// the gathering waves run their 8 rounds without stopping (barriers inside the rounds cost 1.2 us each: every
+// interval then ends with its slowest wave).
+template <int MODE, int FORMULA, int SCHED>
+__global__ __launch_bounds__(kPipeThreads) void interp1_sweep_pipe_kernel(G1Dev g, const double* __restrict__ xq,
+                                                                          double* __restrict__ yq, size_t ntiles,
+                                                                          double extrap, double bscale,
+                                                                          const int* __restrict__ order_flag,
+                                                                          size_t tail, ProbeArgs probe)
+{
+    __shared__ double sq[kSweepTile];
+    __shared__ unsigned hist[2][kSweepBins];
+    __shared__ unsigned gbar[2];
+    if (*order_flag != 0) return;            // queries already ordered locally: the streaming kernel does the work
+    if (threadIdx.x < 2) gbar[threadIdx.x] = 0;
+    const int tid = threadIdx.x & (kPipeGroup - 1);
+    const int grp = threadIdx.x >> 9;        // wave-uniform: waves 0-7 / 8-15
+    const bool last_wg = blockIdx.x == gridDim.x - 1;
+    if (probe.host_mailbox && last_wg && threadIdx.x >= kPipeThreads - 64) order_probe_wave(probe);   // for the next call
+    const long nloc = ntiles > blockIdx.x ? (long)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
+    double q[kSweepK];                       // preparer: the tile's queries; gatherer: its results on their way out
+    unsigned sp2[kSweepK / 2];               // sorted positions of this group's tile, two per register
+    auto load_part = [&](long it, int u0, int u1) {          // vectors u0..u1-1 of the 16 per lane
+        const d2* q2 = reinterpret_cast<const d2*>(xq + ((size_t)blockIdx.x + (size_t)it * gridDim.x) * kSweepTile);
+#pragma unroll
+        for (int u = 0; u < kSweepK / 2; ++u) {
+            if (u >= u0 && u < u1) {
+                const d2 v = __builtin_nontemporal_load(q2 + tid + u * kPipeGroup);
+                q[2 * u] = v.x;
+                q[2 * u + 1] = v.y;
+            }
+        }
+    };
+    auto load_tile = [&](long it) { load_part(it, 0, kSweepK / 2); };
+    for (int b = threadIdx.x; b < 2 * kSweepBins; b += kPipeThreads) (&hist[0][0])[b] = 0;
+    if (SCHED == 0 && grp == 0 && nloc > 0) load_tile(0);
+    pipe_barrier();
+    unsigned* const myhist = hist[grp];
+    unsigned long long* const tdbg = g_pipe_timing;
+    unsigned long long tacc[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
+    unsigned long long tlast = tdbg ? wall_clock64() : 0;
+#define MI_PIPE_STAMP(role, slot)                                       \
+    if (tdbg) {                                                         \
+        const unsigned long long now_ = wall_clock64();                 \
+        tacc[role][slot] += now_ - tlast;                               \
+        tlast = now_;                                                   \
+    }
+    // barrier among the 8 waves of this group only: a monotonic arrival counter in LDS
+    unsigned gb_target = 0;
+    auto group_barrier = [&]() {
+        gb_target += kPipeGroup / 64;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) == 0) atomicAdd(&gbar[grp], 1u);
+        while (*reinterpret_cast<volatile unsigned*>(&gbar[grp]) < gb_target) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
+    };
+    // One step of the schedule: in step `it` the owner of tile `it` (group it & 1) gathers it and the owner of tile
+    // it+1 prepares it.  The two roles are separate code paths run in strict alternation by each group (group 0:
+    // prepare, gather, prepare, ...; group 1: gather, prepare, gather, ...), so that the register allocator sees that
+    // the 64 registers of a tile's queries are dead while its owner gathers.
+    auto gather_step = [&](long it) {        // this group owns tile `it` (it = -1: nothing yet, barriers only)
+        const bool act = it >= 0;
+        // regions are swept up, down, up, ...: L2 still holds the turn-around half.  Lane j of round u handles sorted
+        // position j + 512 u (up) or 16383 - j - 512 u (down).
+        const bool rev = (it & 1) != 0;
+        const int stride = rev ? -kPipeGroup : kPipeGroup;
+        int first = rev ? kSweepTile - 1 - tid : tid;
+        if (act) {
+#pragma unroll 1
+            for (int iv = 0; iv < 4; ++iv) { // eight rounds; the other group prepares its tile meanwhile
+                pipe_gather_rounds<MODE, FORMULA>(g, sq, first, stride, extrap);
+                first += 8 * stride;
+            }
+        }
+        MI_PIPE_STAMP(0, 3)                   // own work: the eight rounds
+        pipe_barrier();
+        MI_PIPE_STAMP(0, 0)                   // waiting for the preparer
+        if (act) {                           // results out of the tile (own queries: positions remembered in sp2)
+#pragma unroll
+            for (int u = 0; u < kSweepK; u += 2) {
+                q[u] = sq[sp2[u / 2] & 0xffffu];
+                q[u + 1] = sq[sp2[u / 2] >> 16];
+                if ((u & 6) == 6) __builtin_amdgcn_sched_barrier(0);   // eight at a time: bounded register pressure
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kSweepK; ++u) q[u] = 0.0;   // explicit definition on every path: q is dead during the rounds
+        }
+        pipe_barrier();
+        MI_PIPE_STAMP(0, 1)                   // ... the other group's tile goes in meanwhile
+        if (act) {                           // results to HBM; nothing waited for
+            d2* o2 = reinterpret_cast<d2*>(yq + ((size_t)blockIdx.x + (size_t)it * gridDim.x) * kSweepTile);
+#pragma unroll
+            for (int u = 0; u < kSweepK / 2; ++u) {
+                d2 v;
+                v.x = q[2 * u];
+                v.y = q[2 * u + 1];
+                __builtin_nontemporal_store(v, o2 + tid + u * kPipeGroup);
+            }
+        }
+        if (SCHED == 0 && it + 2 < nloc) {   // (it = -1: group 1's first tile)
+            load_tile(it + 2);
+        } else {
+#pragma unroll
+            for (int u = 0; u < kSweepK; ++u) q[u] = 0.0;
+        }
+        pipe_barrier();
+        MI_PIPE_STAMP(0, 2)
+    };
+    auto prep_step = [&](long it) {          // this group owns tile it+1 (past the last tile: barriers only)
+        const bool act = it + 1 < nloc;
+        unsigned rank2[kSweepK / 2];         // rank inside the region (histogram ticket), two per register
+#pragma unroll
+        for (int u = 0; u < kSweepK / 2; ++u) rank2[u] = 0;
+        if (act) {
+            if (SCHED == 1) {
+                load_part(it + 1, 0, kSweepK / 4);
+                __builtin_amdgcn_s_sleep(100);               // ~2.7 us
+                load_part(it + 1, kSweepK / 4, kSweepK / 2);
+            } else if (SCHED == 2) {
+#pragma unroll
+                for (int u = 0; u < kSweepK / 2; ++u) {
+                    load_part(it + 1, u, u + 1);
+                    __builtin_amdgcn_s_sleep(24);            // ~0.65 us apart: the tile arrives over ~10 us
+                }
+            }
+            MI_PIPE_STAMP(1, 3)               // loads issued
+            // region histogram (own histogram, cleared in the previous step)
+#pragma unroll
+            for (int u = 0; u < kSweepK; u += 2) {
+                const unsigned r0 = atomicAdd(&myhist[sweep_bin(q[u], g.xmin, bscale)], 1u);
+                const unsigned r1 = atomicAdd(&myhist[sweep_bin(q[u + 1], g.xmin, bscale)], 1u);
+                rank2[u / 2] = r0 | (r1 << 16);
+                if ((u & 6) == 6) __builtin_amdgcn_sched_barrier(0);
+            }
+            group_barrier();
+            if (tid < 64) {                  // exclusive prefix over the regions (one wave, 64 at a time)
+                unsigned run = 0;
+#pragma unroll
+                for (int base = 0; base < kSweepBins; base += 64) {
+                    const unsigned v = myhist[base + tid];
+                    unsigned incl = v;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const unsigned o = __shfl_up(incl, off, 64);
+                        if (tid >= off) incl += o;
+                    }
+                    myhist[base + tid] = run + incl - v;
+                    run += __shfl(incl, 63, 64);
+                }
+            }
+            group_barrier();
+#pragma unroll
+            for (int u = 0; u < kSweepK; u += 2) {   // sorted positions
+                // the region is recomputed from the query (three instructions) rather than kept: handed through an
+                // empty asm so that the compiler does not keep the 32 fp64 products of the histogram pass alive
+                double qa = q[u], qb = q[u + 1];
+                asm volatile("" : "+v"(qa), "+v"(qb));
+                const unsigned p0 = myhist[sweep_bin(qa, g.xmin, bscale)] + (rank2[u / 2] & 0xffffu);
+                const unsigned p1 = myhist[sweep_bin(qb, g.xmin, bscale)] + (rank2[u / 2] >> 16);
+                sp2[u / 2] = p0 | (p1 << 16);
+                if ((u & 6) == 6) __builtin_amdgcn_sched_barrier(0);
+            }
+            MI_PIPE_STAMP(1, 5)               // sorted
+        } else {
+#pragma unroll
+            for (int u = 0; u < kSweepK / 2; ++u) sp2[u] = 0;
+        }
+        pipe_barrier();                      // the gather rounds of the other group are over
+        MI_PIPE_STAMP(1, 0)                   // waiting for the gatherer
+        if (act) {
+            for (int b = tid; b < kSweepBins; b += kPipeGroup) myhist[b] = 0;   // every lane read its region bases before the barrier
+        }
+        pipe_barrier();                      // (the gatherer has taken its results out of the tile)
+        MI_PIPE_STAMP(1, 1)
+        if (act) {                           // this group's tile goes in
+#pragma unroll
+            for (int u = 0; u < kSweepK; u += 2) {
+                sq[sp2[u / 2] & 0xffffu] = q[u];
+                sq[sp2[u / 2] >> 16] = q[u + 1];
+                if ((u & 6) == 6) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        pipe_barrier();
+        MI_PIPE_STAMP(1, 2)
+    };
+    if (grp == 0) {
+        for (long it = -1;;) {
+            prep_step(it);
+            if (++it >= nloc) break;
+            gather_step(it);
+            if (++it >= nloc) break;
+        }
+    } else {
+        for (long it = -1;;) {
+            gather_step(it);
+            if (++it >= nloc) break;
+            prep_step(it);
+            if (++it >= nloc) break;
+        }
+    }
+#undef MI_PIPE_STAMP
+    if (tdbg && tid == 0) {
+        for (int r = 0; r < 2; ++r)
+            for (int k = 0; k < 6; ++k) tdbg[((size_t)blockIdx.x * 2 + grp) * 12 + r * 6 + k] = tacc[r][k];
+    }
+    if (tail && last_wg && grp == 0) {       // ragged tail (< one tile), four queries per lane at a time
+        const double* tq = xq + ntiles * kSweepTile;
+        double* to = yq + ntiles * kSweepTile;
+#pragma unroll 1
+        for (int u = 0; u < kSweepK; u += 4) {
+            double qq[4], rr[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const size_t i = (size_t)tid + (size_t)(u + w) * kPipeGroup;
+                qq[w] = i < tail ? tq[i] : 0.0;
+            }
+            eval_batch<MODE, 4, FORMULA>(g, qq, rr, extrap);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const size_t i = (size_t)tid + (size_t)(u + w) * kPipeGroup;
                 if (i < tail) to[i] = rr[w];
             }
         }
@@ -628,6 +935,19 @@ mi_status launch_vec(mi_ctx* ctx, const G1Dev& d, const double* xq, double* yq, 
     if (order_flag)
         return launch_vec_shape<MODE, FORMULA, MI_INTERP1_GATED_BLOCK, MI_INTERP1_GATED_VPL>(ctx, d, xq, yq, nq, extrap, order_flag, probe);
     return launch_vec_shape<MODE, FORMULA, kBlock, MI_INTERP1_VPL>(ctx, d, xq, yq, nq, extrap, nullptr, probe);
+}
+
+// MI_SWEEP_VARIANT = 1 (default): one 512-lane workgroup per CU, the phases of a tile one after the other;
+// 2: the pipelined form (two wave groups per CU swapping roles; 0.67-0.73 ms against 0.71 ms, see DESIGN.md section 4:
+// not consistently faster, kept as an A-B hook).  Read once.
+inline int sweep_variant()
+{
+    static const int v = [] {
+        const char* e = getenv("MI_SWEEP_VARIANT");
+        const int x = e ? atoi(e) : 1;
+        return (x == 1 || x == 2) ? x : 1;
+    }();
+    return v;
 }
 
 template <int MODE, int FORMULA = 0>
@@ -709,6 +1029,21 @@ mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, size_t table_bytes, const dou
         return MI_OK;
     }
     // one launch: sort-and-gather tiles, the ragged tail, and the probe for the next call (flags[0] is a constant 0)
+    if (sweep_variant() == 2) {
+        const unsigned pgrid = (unsigned)std::min<size_t>(ntiles, (size_t)cus);   // one 1024-lane workgroup per CU
+        static const int sched = [] { const char* e = getenv("MI_SWEEP_SCHED"); return e ? atoi(e) : 0; }();   // A-B hook
+        if (sched == 1)
+            hipLaunchKernelGGL((interp1_sweep_pipe_kernel<MODE, FORMULA, 1>), dim3(pgrid), dim3(kPipeThreads), 0, ctx->stream, d, xq, yq,
+                               ntiles, extrap, bscale, flags, nq - head, probe);
+        else if (sched == 2)
+            hipLaunchKernelGGL((interp1_sweep_pipe_kernel<MODE, FORMULA, 2>), dim3(pgrid), dim3(kPipeThreads), 0, ctx->stream, d, xq, yq,
+                               ntiles, extrap, bscale, flags, nq - head, probe);
+        else
+        hipLaunchKernelGGL((interp1_sweep_pipe_kernel<MODE, FORMULA, 0>), dim3(pgrid), dim3(kPipeThreads), 0, ctx->stream, d, xq, yq,
+                           ntiles, extrap, bscale, flags, nq - head, probe);
+        MI_LAUNCH_CHECK(ctx, "interp1 pipelined region-sweep kernel");
+        return MI_OK;
+    }
     hipLaunchKernelGGL((interp1_sweep_kernel<MODE, FORMULA>), dim3(grid), dim3(kSweepThreads), 0, ctx->stream, d, xq, yq,
                        ntiles, extrap, bscale, flags, nq - head, probe);
     MI_LAUNCH_CHECK(ctx, "interp1 region-sweep kernel");
@@ -1021,6 +1356,15 @@ mi_status mi_grid1_destroy(mi_grid1* g)
     return MI_OK;
 }
 
+mi_status mi_debug_sweep_timing(mi_ctx* ctx, unsigned long long* ticks_dev)
+{
+    MI_REQUIRE(ctx, ctx != nullptr, "mi_debug_sweep_timing: ctx is NULL");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MI_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_timing), &ticks_dev, sizeof(ticks_dev)));
+    return MI_OK;
+}
+
 mi_status mi_grid1_info(const mi_grid1* g, size_t* n_nodes, int* mode, size_t* table_bytes)
 {
     MI_REQUIRE(nullptr, g != nullptr, "mi_grid1_info: grid is NULL");
@@ -1037,6 +1381,7 @@ mi_status mi_interp1_f64_dev(mi_ctx* ctx, const mi_grid1* g, const double* xq, d
     MI_REQUIRE(ctx, xq && yq, "mi_interp1_f64_dev: NULL query/result pointer");
     MI_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq)) & 7u) == 0,
                "mi_interp1_f64_dev: pointers must be 8-byte aligned");
+    MI_HIP(ctx, hipSetDevice(ctx->device));   // a process may hold contexts on several devices (mi_group)
     switch (g->mode) {
         case 0:
             if (g->d.formula == 1) return launch_mode<0, 1>(ctx, g->d, g->table_bytes, xq, yq, nq, extrap);
@@ -1078,25 +1423,30 @@ mi_status mi_interp1_f64_host(mi_ctx* ctx, const mi_grid1* g, const double* xq, 
     // Asynchronous copies need page-locked host memory: pin the caller's arrays for the duration of the call (the
     // runtime keeps the pinning of a range it has seen before, so this costs nothing from the second call on; a
     // range that cannot be pinned, or is pinned already, simply takes the blocking path inside hipMemcpyAsync).
-    const bool pin_in = hipHostRegister(const_cast<double*>(xq), bytes, hipHostRegisterDefault) == hipSuccess;
-    const bool pin_out = hipHostRegister(yq, bytes, hipHostRegisterDefault) == hipSuccess;
-    (void)hipGetLastError();
+    const bool pin_in = mi::pin_host(xq, bytes), pin_out = mi::pin_host(yq, bytes);
     const double* din = (const double*)ctx->scratch[0];
     double* dout = (double*)ctx->scratch[1];
-    for (size_t off = 0; off < nq; off += chunk) {
+    // No early return between here and the unpinning below: a failing call leaves the loop, both streams are
+    // drained (copies already queued still write into the caller's arrays), and only then are the ranges released.
+    hipError_t herr = hipSuccess;
+    const char* what = "";
+    if (getenv("MI_TEST_FAIL_HOST_CHUNK")) { herr = hipErrorUnknown; what = "MI_TEST_FAIL_HOST_CHUNK (error-path test hook)"; }
+    for (size_t off = 0; off < nq && herr == hipSuccess && st == MI_OK; off += chunk) {
         const size_t m = std::min(chunk, nq - off);
-        MI_HIP(ctx, hipMemcpyAsync((void*)(din + off), xq + off, m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        herr = hipMemcpyAsync((void*)(din + off), xq + off, m * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (herr != hipSuccess) { what = "upload of a query chunk"; break; }
         st = mi_interp1_f64_dev(ctx, g, din + off, dout + off, m, extrap);
         if (st != MI_OK) break;
-        MI_HIP(ctx, hipEventRecord(ctx->aux_event, ctx->stream));
-        MI_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_event, 0));
-        MI_HIP(ctx, hipMemcpyAsync(yq + off, dout + off, m * sizeof(double), hipMemcpyDeviceToHost, ctx->aux_stream));
+        herr = hipEventRecord(ctx->aux_event, ctx->stream);
+        if (herr == hipSuccess) herr = hipStreamWaitEvent(ctx->aux_stream, ctx->aux_event, 0);
+        if (herr == hipSuccess) herr = hipMemcpyAsync(yq + off, dout + off, m * sizeof(double), hipMemcpyDeviceToHost, ctx->aux_stream);
+        if (herr != hipSuccess) what = "download of a result chunk";
     }
-    hipError_t e1 = hipStreamSynchronize(ctx->stream), e2 = hipStreamSynchronize(ctx->aux_stream);
-    if (pin_in) (void)hipHostUnregister(const_cast<double*>(xq));
-    if (pin_out) (void)hipHostUnregister(yq);
-    (void)hipGetLastError();   // an unregister that fails (range already unpinned by the runtime) must not poison later launch checks
+    const hipError_t e1 = hipStreamSynchronize(ctx->stream), e2 = hipStreamSynchronize(ctx->aux_stream);
+    if (pin_in) mi::unpin_host(xq);
+    if (pin_out) mi::unpin_host(yq);
     if (st != MI_OK) return st;
+    if (herr != hipSuccess) return mi::fail(ctx, MI_ERR_HIP, "mi_interp1_f64_host: %s failed: %s", what, hipGetErrorString(herr));
     MI_HIP(ctx, e1);
     MI_HIP(ctx, e2);
     return MI_OK;

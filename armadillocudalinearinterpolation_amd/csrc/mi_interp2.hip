@@ -338,6 +338,7 @@ mi_status mi_interp2_f64_dev(mi_ctx* ctx, const mi_grid2* g, const double* xq, c
     MI_REQUIRE(ctx, xq && yq && zq, "mi_interp2_f64_dev: NULL query/result pointer");
     const uintptr_t a = reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq) | reinterpret_cast<uintptr_t>(zq);
     MI_REQUIRE(ctx, (a & 7u) == 0, "mi_interp2_f64_dev: pointers must be 8-byte aligned");
+    MI_HIP(ctx, hipSetDevice(ctx->device));   // a process may hold contexts on several devices (mi_group)
     const bool vec = (a & 15u) == 0;
     const size_t lanes = vec ? (nq >> 1) + (nq & 1) : nq;
     const size_t grid = (lanes + kBlock - 1) / kBlock;
@@ -375,27 +376,30 @@ mi_status mi_interp2_f64_host(mi_ctx* ctx, const mi_grid2* g, const double* xq, 
     // chunked and pinned like mi_interp1_f64_host: the copy back of chunk k overlaps the uploads of chunk k+1
     st = mi::ensure_aux_stream(ctx);
     if (st != MI_OK) return st;
-    const bool pin_x = hipHostRegister(const_cast<double*>(xq), bytes, hipHostRegisterDefault) == hipSuccess;
-    const bool pin_y = hipHostRegister(const_cast<double*>(yq), bytes, hipHostRegisterDefault) == hipSuccess;
-    const bool pin_z = hipHostRegister(zq, bytes, hipHostRegisterDefault) == hipSuccess;
-    (void)hipGetLastError();
+    const bool pin_x = mi::pin_host(xq, bytes), pin_y = mi::pin_host(yq, bytes), pin_z = mi::pin_host(zq, bytes);
     double *dx = (double*)ctx->scratch[0], *dy = (double*)ctx->scratch[1], *dz = (double*)ctx->scratch[2];
-    for (size_t off = 0; off < nq; off += chunk) {
+    // as in mi_interp1_f64_host: no early return before both streams are drained and the ranges released
+    hipError_t herr = hipSuccess;
+    const char* what = "";
+    if (getenv("MI_TEST_FAIL_HOST_CHUNK")) { herr = hipErrorUnknown; what = "MI_TEST_FAIL_HOST_CHUNK (error-path test hook)"; }
+    for (size_t off = 0; off < nq && herr == hipSuccess && st == MI_OK; off += chunk) {
         const size_t m = std::min(chunk, nq - off);
-        MI_HIP(ctx, hipMemcpyAsync(dx + off, xq + off, m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        MI_HIP(ctx, hipMemcpyAsync(dy + off, yq + off, m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        herr = hipMemcpyAsync(dx + off, xq + off, m * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (herr == hipSuccess) herr = hipMemcpyAsync(dy + off, yq + off, m * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (herr != hipSuccess) { what = "upload of a query chunk"; break; }
         st = mi_interp2_f64_dev(ctx, g, dx + off, dy + off, dz + off, m, extrap);
         if (st != MI_OK) break;
-        MI_HIP(ctx, hipEventRecord(ctx->aux_event, ctx->stream));
-        MI_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_event, 0));
-        MI_HIP(ctx, hipMemcpyAsync(zq + off, dz + off, m * sizeof(double), hipMemcpyDeviceToHost, ctx->aux_stream));
+        herr = hipEventRecord(ctx->aux_event, ctx->stream);
+        if (herr == hipSuccess) herr = hipStreamWaitEvent(ctx->aux_stream, ctx->aux_event, 0);
+        if (herr == hipSuccess) herr = hipMemcpyAsync(zq + off, dz + off, m * sizeof(double), hipMemcpyDeviceToHost, ctx->aux_stream);
+        if (herr != hipSuccess) what = "download of a result chunk";
     }
-    hipError_t e1 = hipStreamSynchronize(ctx->stream), e2 = hipStreamSynchronize(ctx->aux_stream);
-    if (pin_x) (void)hipHostUnregister(const_cast<double*>(xq));
-    if (pin_y) (void)hipHostUnregister(const_cast<double*>(yq));
-    if (pin_z) (void)hipHostUnregister(zq);
-    (void)hipGetLastError();   // an unregister that fails (range already unpinned by the runtime) must not poison later launch checks
+    const hipError_t e1 = hipStreamSynchronize(ctx->stream), e2 = hipStreamSynchronize(ctx->aux_stream);
+    if (pin_x) mi::unpin_host(xq);
+    if (pin_y) mi::unpin_host(yq);
+    if (pin_z) mi::unpin_host(zq);
     if (st != MI_OK) return st;
+    if (herr != hipSuccess) return mi::fail(ctx, MI_ERR_HIP, "mi_interp2_f64_host: %s failed: %s", what, hipGetErrorString(herr));
     MI_HIP(ctx, e1);
     MI_HIP(ctx, e2);
     return MI_OK;

@@ -187,9 +187,16 @@ __global__ __launch_bounds__(kBlock) void mean_stage2_kernel(const Partials* __r
         for (int w = 0; w < kBlock / 64; ++w) s += lds_sum[w][threadIdx.x];
         // reference quirk: accept[0] holds the count when the mean runs, so
         // realisation 0 is summed iff count == 1 (EventDrivenMap.cu:800-802,:817)
-        if (quirk && total == 1u) s += (double)part->x_real0[threadIdx.x];
+        const double x0 = quirk ? (double)part->x_real0[threadIdx.x] : 0.0;
+        // partial block [sums | count | x0] (MI_EDM_PARTIAL_LEN): the sums WITHOUT that re-inclusion, so that the
+        // blocks of several shards add up and the rule is applied once, to the total (mi_edm_residual_from_sums)
+        if (sums_out) {
+            sums_out[threadIdx.x] = s;
+            sums_out[nspikes + 1 + threadIdx.x] = x0;
+            if (threadIdx.x == 0) sums_out[nspikes] = (double)total;
+        }
+        if (quirk && total == 1u) s += x0;
         mean[threadIdx.x] = (float)(s / (double)total);    // one rounding: exact for identical realisations
-        if (sums_out) sums_out[threadIdx.x] = s;
         if (threadIdx.x == 0 && count_out) *count_out = total;
     }
 }
@@ -212,6 +219,7 @@ mi_status mi_restrict_f32_dev(mi_ctx* ctx, const float* t0, const uint16_t* i0, 
     if (n == 0) return MI_OK;
     MI_REQUIRE(ctx, t0 && i0 && t1 && i1 && out, "mi_restrict_f32_dev: NULL array pointer");
     MI_REQUIRE(ctx, ngrid > 0, "mi_restrict_f32_dev: ngrid must be positive");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
     const float h = (2.0f * L) / (float)ngrid;
     const uintptr_t a16 = reinterpret_cast<uintptr_t>(t0) | reinterpret_cast<uintptr_t>(t1) | reinterpret_cast<uintptr_t>(out);
     const uintptr_t a8 = reinterpret_cast<uintptr_t>(i0) | reinterpret_cast<uintptr_t>(i1);

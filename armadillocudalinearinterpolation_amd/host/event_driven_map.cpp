@@ -47,7 +47,7 @@ EventDrivenMap::EventDrivenMap(const arma::vec* pParameters, unsigned int noReal
     const auto now = std::chrono::steady_clock::now().time_since_epoch().count();
     p_.seed = static_cast<unsigned long long>(now);      // mSeed = clock(), EventDrivenMap.cu:104
     must(mi_edm_create(ctx_, &p_, &edm_), ctx_, "mi_edm_create");
-    partial_.set_size(p_.n_spikes + 1);
+    partial_.set_size(MI_EDM_PARTIAL_LEN(p_.n_spikes));
     partial_.zeros();
 }
 
@@ -67,7 +67,7 @@ void EventDrivenMap::ComputeF(const arma::vec& u, arma::vec& f)
 {
     assert(u.n_elem == p_.n_spikes);
     f.set_size(p_.n_spikes);
-    partial_.set_size(p_.n_spikes + 1);
+    partial_.set_size(MI_EDM_PARTIAL_LEN(p_.n_spikes));
     must(mi_edm_compute_f(edm_, u.memptr(), f.memptr(), partial_.memptr()), ctx_, "mi_edm_compute_f");
     if (debug_) Dump();
 }
@@ -195,6 +195,13 @@ void EventDrivenMap::SetRealisationOffset(unsigned int offset)
     Push();
 }
 
+void EventDrivenMap::SetMeanQuirk(bool on)
+{
+    p_.mean_quirk = on ? 1 : 0;
+    Push();
+    if (!quiet_) std::cout << (on ? "Averaging as the reference does (realisation 0 left out of the sum)" : "Averaging with the true mean") << std::endl;
+}
+
 void EventDrivenMap::SetDedupIdentical(bool on)
 {
     p_.dedup_identical = on ? 1u : 0u;
@@ -227,6 +234,9 @@ void EventDrivenMap::Dump()
     save_column(d + "testAcceptFlag.dat", R, as_float(acc).data());
     save_column(d + "testAverages.dat", SR, xr.data());                         // :485-493: Restrict output
     std::vector<float> mean(S);
-    for (size_t m = 0; m < S; ++m) mean[m] = static_cast<float>(partial_[m] / partial_[S]);
+    for (size_t m = 0; m < S; ++m) {   // the averaging rule of mi_edm_residual_from_sums
+        const double sum = partial_[m] + ((p_.mean_quirk != 0 && partial_[S] == 1.0) ? partial_[S + 1 + m] : 0.0);
+        mean[m] = static_cast<float>(sum / partial_[S]);
+    }
     save_column(d + "testAveraged.dat", S, mean.data());                        // :495-503
 }

@@ -35,13 +35,21 @@ class EventDrivenMap : public AbstractNonlinearProblem, public AbstractBatchedNo
     void PostProcess() override;                     // = SetNewSeed (EventDrivenMap.cu:343-346)
     void SetDebugFlag(const bool val);               // Save* dumps, EventDrivenMap.cu:406-503
 
+    // Averaging over realisations.  true (default): exactly what the reference computes -- CountRealisationsKernel
+    // overwrites accept[0] with the count (EventDrivenMap.cu:800-802), so the reduction (:817) leaves realisation 0 out
+    // of the sum while :822 divides by the full count (unless only one realisation was accepted).  false: the true mean
+    // over the accepted realisations.
+    void SetMeanQuirk(bool on);
+    bool MeanQuirk() const { return p_.mean_quirk != 0; }
+
     // extensions (not in the reference)
     void SetMathMode(int mode);                      // MI_EDM_MATH_EXACT / MI_EDM_MATH_FAST
     void SetRealisationOffset(unsigned int offset);  // this rank's first global realisation (multi-GPU shards)
     void SetDedupIdentical(bool on);                 // sigma == 0: evolve one realisation, replicate (bit-identical)
     void SetDebugDirectory(const std::string& dir) { debug_dir_ = dir; }
     void SetQuiet(bool q) { quiet_ = q; }
-    // un-normalised accepted sums (S values) + accepted count of the last ComputeF, for an all-reduce
+    // partial block of the last ComputeF, MI_EDM_PARTIAL_LEN(S) = 2S+1 values [un-normalised accepted sums | accepted
+    // count | restricted position of realisation 0 (reference averaging, shard with offset 0)]: what an all-reduce sums
     const arma::vec& LastPartialSums() const { return partial_; }
     void ResidualFromSums(const arma::vec& u, const arma::vec& sums_and_count, arma::vec& f) const;
     const mi_edm_params& Parameters() const { return p_; }

@@ -4,8 +4,9 @@
   replicated; no collective is needed unless the caller wants the whole result vector on every rank
   (all_gather_results).
 * EventDrivenMap::ComputeF: realisations split into contiguous per-rank shards (the realisation is already
-  the unit of work, EventDrivenMap.cu:196); the only exchange is an all-reduce(sum) of S fp64 partial sums
-  and the accepted count -- not an all-gather.
+  the unit of work, EventDrivenMap.cu:196); the only exchange is an all-reduce(sum) of the partial block
+  [S fp64 sums | accepted count | S restricted positions of realisation 0] (MI_EDM_PARTIAL_LEN(S) = 2S+1
+  scalars) -- not an all-gather.
 """
 import numpy as np
 
@@ -38,8 +39,9 @@ def all_gather_results(local, world_sizes=None):
 class ShardedResidual:
     """ComputeF over realisations sharded across ranks.
 
-    local_partial(Z, lo, hi) -> float64[S+1]: this rank's un-normalised per-spike sums over its accepted
-    realisations [lo, hi) followed by its accepted count.  On the GPU that is
+    local_partial(Z, lo, hi) -> float64[2S+1]: this rank's partial block -- un-normalised per-spike sums over its
+    accepted realisations [lo, hi), its accepted count, and (rank with lo == 0, reference averaging) the restricted
+    position of realisation 0, which the reference leaves out of the sum unless the count is 1.  On the GPU that is
     EventDrivenMap(n_real=hi-lo, real_offset=lo).ComputeF(Z, want_partial=True)[1]; tests inject the oracle.
     finish(Z, sums_and_count) -> f: mi_edm_residual_from_sums (host arithmetic of EventDrivenMap.cu:237-239).
     """
@@ -57,5 +59,5 @@ class ShardedResidual:
         part = np.asarray(self._local(Z, self.lo, self.hi), dtype=np.float64)
         t = torch.from_numpy(part.copy()).to(self._device)
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)           # S+1 scalars: latency-bound, tens of us on xGMI
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)           # 2S+1 scalars: latency-bound, tens of us on xGMI
         return self._finish(Z, t.cpu().numpy())

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MI355_INTERP_ABI_VERSION 1
+#define MI355_INTERP_ABI_VERSION 2
 
 typedef int mi_status;
 enum {
@@ -74,6 +74,13 @@ mi_status mi_ctx_own_stream(mi_ctx* ctx);
 mi_status mi_ctx_synchronize(mi_ctx* ctx);
 const char* mi_last_error(const mi_ctx* ctx);
 int mi_abi_version(void);
+/* Test hook: number of caller host ranges the library currently keeps page-locked on behalf of host-convenience calls
+ * in flight (mi_interp1_f64_host, mi_interp2_f64_host); 0 once every such call has returned, on success or error. */
+size_t mi_debug_pinned_ranges(void);
+/* Test / profiling hook: phase timing of the pipelined region-sweep kernel.  ticks_dev: device array of
+ * [workgroups][2 groups][2 roles: gather, prepare][6 schedule intervals] 64-bit counters (wall_clock64, 100 MHz) that the
+ * kernel overwrites at the end of every launch; NULL switches the stamps off again (the default). */
+mi_status mi_debug_sweep_timing(mi_ctx* ctx, unsigned long long* ticks_dev);
 /* Hint about the order of the query vectors handed to mi_interp1_f64_dev on this context.  Unordered queries
  * over a table larger than L2 are processed by a "region sweep" kernel (workgroup-local ordering by table region
  * in LDS; results keep the caller's order), ordered/clustered ones by the plain streaming kernel.  AUTO decides on
@@ -180,9 +187,18 @@ mi_status mi_restrict_f32_host(mi_ctx* ctx, const float* t0, const uint16_t* i0,
  * (EventDrivenMap.cu:787-824): mean over accepted realisations, per spike.
  * x: f32[nspikes*nreal] ([spike][realisation]), accept: u32[nreal] (0/1).
  * mean_dev: f32[nspikes]; count_dev: u32[1]; sums_dev (optional, may be
- * NULL): f64[nspikes] un-normalised sums for a multi-GPU all-reduce.
- * quirk != 0 reproduces the reference's accept[0] clobber (realisation 0 is
- * dropped from the sums unless count == 1).  `accept` is never modified. */
+ * NULL): f64[MI_EDM_PARTIAL_LEN(nspikes)], the partial block
+ *   [ sum_m over the accepted realisations, m < nspikes | accepted count | x0_m ]
+ * whose element-wise sum over the shards of a multi-GPU run is what
+ * mi_edm_residual_from_sums turns into the mean.
+ * quirk != 0 reproduces the reference's accept[0] clobber
+ * (EventDrivenMap.cu:800-802 overwrites accept[0] with the count, :817 then
+ * tests accept[index]==1): realisation 0 is left out of the sums -- and
+ * counted in the divisor (:822) -- unless count == 1, when it is summed whatever
+ * its flag was.  In the partial block the sums never contain realisation 0 when
+ * quirk is set and x0_m holds its restricted position (0 without quirk), so the
+ * count == 1 rule can be applied to the total.  `accept` is never modified. */
+#define MI_EDM_PARTIAL_LEN(nspikes) (2 * (nspikes) + 1)
 mi_status mi_masked_mean_f32_dev(mi_ctx* ctx, const float* x, const uint32_t* accept, size_t nreal,
                                  size_t nspikes, int quirk, float* mean_dev, uint32_t* count_dev,
                                  double* sums_dev);
@@ -211,7 +227,12 @@ typedef struct mi_edm_params {
     float beta_stddev;                 /* mParStdDev (EventDrivenMap.cu:105)     */
     uint64_t seed;                     /* mSeed                                  */
     int math_mode;                     /* MI_EDM_MATH_EXACT or MI_EDM_MATH_FAST  */
-    int mean_quirk;                    /* reproduce the accept[0] clobber        */
+    int mean_quirk;                    /* default 1: average exactly as the
+                                          reference does (EventDrivenMap.cu:800-802,
+                                          :817,:822: realisation 0 is left out of the
+                                          sum but counted in the divisor, unless only
+                                          one realisation was accepted); 0: the true
+                                          mean over the accepted realisations        */
     uint32_t max_events;               /* hard bound on events per realisation
                                           (termination guarantee; default 2^20)  */
     uint32_t real_offset;              /* global index of this shard's first
@@ -235,9 +256,12 @@ mi_status mi_edm_destroy(mi_edm* e);
 mi_status mi_edm_set_params(mi_edm* e, const mi_edm_params* p);
 /* ComputeF (EventDrivenMap.cu:154-240).  z: host, n_spikes doubles (c, Z1..);
  * f: host, n_spikes doubles.  partial (optional, may be NULL): host,
- * n_spikes+1 doubles receiving this device's un-normalised sums and accepted
- * count so that a caller sharding realisations over GPUs can all-reduce them;
- * when partial is non-NULL f is still the single-device residual. */
+ * MI_EDM_PARTIAL_LEN(n_spikes) doubles receiving this device's partial block
+ * [sums | accepted count | x0] (see mi_masked_mean_f32_dev) so that a caller
+ * sharding realisations over GPUs can all-reduce them (the shard with
+ * real_offset == 0 holds realisation 0 of the ensemble and is the only one that
+ * applies mean_quirk); when partial is non-NULL f is still the single-device
+ * residual. */
 mi_status mi_edm_compute_f(mi_edm* e, const double* z, double* f, double* partial);
 /* The same in two halves: _begin enqueues the whole evaluation on the context's stream and returns at once,
  * _end waits for it and forms f (and partial).  Independent evaluations -- the columns of NewtonSolver's
@@ -246,7 +270,9 @@ mi_status mi_edm_compute_f(mi_edm* e, const double* z, double* f, double* partia
  * handle at a time. */
 mi_status mi_edm_compute_f_begin(mi_edm* e, const double* z);
 mi_status mi_edm_compute_f_end(mi_edm* e, double* f, double* partial);
-/* f from all-reduced partial sums (host arithmetic of EventDrivenMap.cu:237-239) */
+/* f from the all-reduced (element-wise summed) partial blocks, MI_EDM_PARTIAL_LEN(n_spikes) doubles: the
+ * averaging rule of p->mean_quirk applied to the totals, then the host arithmetic of EventDrivenMap.cu:237-239.
+ * With one shard this reproduces mi_edm_compute_f's f bit for bit. */
 mi_status mi_edm_residual_from_sums(const mi_edm_params* p, const double* z, const double* sums_and_count,
                                     double* f);
 /* Debug taps (SaveLift/SaveEvolve/SaveRestrict, EventDrivenMap.cu:406-503):
@@ -264,6 +290,64 @@ mi_status mi_edm_last_timings(mi_edm* e, float ms[4]);
  * oracle/edm_oracle.c bit for bit.  Device pointers; b_dev may be NULL. */
 mi_status mi_edm_math_probe(mi_ctx* ctx, int math_mode, int op, const float* a_dev, const float* b_dev,
                             float* out_dev, size_t n);
+
+/* ---- several GPUs of one node, one host process ----------------------------
+ * The reference is single-GPU (EventDrivenMap.cu:80-94 allocates on the current
+ * device, Driver.cu:20 builds one problem); BASELINE configs 4-5 shard the
+ * realisation axis -- and the query axis of the table interpolation -- over the
+ * GPUs of a node.  A group owns one context (device + stream of
+ * its own) per shard.  Host code keeps the reference's shape: ONE ComputeF per
+ * residual (AbstractNonlinearProblem.hpp:11, Driver.cu:71) -- see
+ * mi_group_edm_compute_f -- and one call per interpolation.
+ * devices: ndev ordinals, or NULL for 0..ndev-1.  Naming a device more than once
+ * is allowed (rehearsal of the shard arithmetic on a box with fewer GPUs); such a
+ * group cannot use RCCL and moves data with device-to-device copies instead. */
+typedef struct mi_group mi_group;
+typedef struct mi_group_grid1 mi_group_grid1;
+typedef struct mi_group_edm mi_group_edm;
+mi_status mi_group_create(int ndev, const int* devices, mi_group** out);
+mi_status mi_group_destroy(mi_group* g);
+int mi_group_size(const mi_group* g);
+mi_ctx* mi_group_ctx(mi_group* g, int rank);          /* shard `rank`'s context (owned by the group) */
+mi_status mi_group_synchronize(mi_group* g);
+/* contiguous, balanced split of n units over `world` shards: shard `rank` = [lo, hi); the first n % world shards get
+ * one extra unit.  Host arithmetic only. */
+void mi_shard_bounds(size_t n, int rank, int world, size_t* lo, size_t* hi);
+/* How mi_group_edm_compute_f adds the shards' partial blocks: on the host, where they already are (default), or with
+ * ncclAllReduce on the devices (RCCL over xGMI; distinct devices only). */
+#define MI_GROUP_REDUCE_HOST 0
+#define MI_GROUP_REDUCE_RCCL 1
+mi_status mi_group_set_reduce(mi_group* g, int mode);
+
+/* 1-D table replicated on every device of the group (x, y: host pointers; flags as mi_grid1_create). */
+mi_status mi_group_grid1_create(mi_group* g, const double* x, const double* y, size_t n, unsigned flags,
+                                mi_group_grid1** out);
+mi_status mi_group_grid1_destroy(mi_group_grid1* t);
+/* Query shards from / to host arrays (the arma::vec-facing form): shard r = mi_shard_bounds(nq, r, P) is uploaded to,
+ * evaluated on and downloaded from device r, all shards concurrently; returns when yq is complete. */
+mi_status mi_group_interp1_f64_host(mi_group* g, const mi_group_grid1* t, const double* xq, double* yq, size_t nq,
+                                    double extrap_val);
+/* Device-resident shards: xq_dev[r] / yq_dev[r] point to nq_per_shard doubles on device r.  Asynchronous (each shard on
+ * its context's stream; mi_group_synchronize waits).  gathered_dev (optional, may be NULL): gathered_dev[r] is a buffer
+ * of P * nq_per_shard doubles on device r that receives EVERY shard's results (shard s at offset s * nq_per_shard;
+ * in place when yq_dev[r] == gathered_dev[r] + r * nq_per_shard): an RCCL all-gather over xGMI behind the kernels. */
+mi_status mi_group_interp1_f64_dev(mi_group* g, const mi_group_grid1* t, const double* const* xq_dev,
+                                   double* const* yq_dev, size_t nq_per_shard, double extrap_val,
+                                   double* const* gathered_dev);
+
+/* EventDrivenMap with the realisations sharded over the group: p->n_real is the TOTAL (>= group size); shard r evolves
+ * realisations [lo_r, hi_r) = mi_shard_bounds(n_real, r, P) with real_offset = p->real_offset + lo_r, so the per-neuron
+ * draws -- and therefore every result -- are those of the unsharded ensemble. */
+mi_status mi_group_edm_create(mi_group* g, const mi_edm_params* p, mi_group_edm** out);
+mi_status mi_group_edm_destroy(mi_group_edm* e);
+mi_status mi_group_edm_set_params(mi_group_edm* e, const mi_edm_params* p);
+/* ComputeF (EventDrivenMap.cu:154-240) over all shards: every device runs lift -> evolve -> restrict -> partial sums
+ * concurrently, the partial blocks (MI_EDM_PARTIAL_LEN(n_spikes) doubles per shard) are added (see
+ * mi_group_set_reduce) and f is formed from the totals exactly as mi_edm_residual_from_sums does.  z, f: host,
+ * n_spikes doubles; partial_total (optional): the summed block. */
+mi_status mi_group_edm_compute_f(mi_group_edm* e, const double* z, double* f, double* partial_total);
+mi_edm* mi_group_edm_shard(mi_group_edm* e, int rank);               /* shard handle, e.g. for mi_edm_debug_read */
+mi_status mi_group_edm_shard_bounds(const mi_group_edm* e, int rank, size_t* lo, size_t* hi);
 
 #ifdef __cplusplus
 }

@@ -422,19 +422,26 @@ int orc_edm_compute_f(const orc_edm_params* P, const double* Z, double* f, uint1
     orc_restrict_f32(t0, i0, t1, i1, P->time_horizon, P->L, N, xr, SR);
     float mean[ORC_MAX_SPIKES];
     uint32_t count = 0;
-    orc_masked_mean_f32(xr, acc, R, S, P->mean_quirk, mean, &count);
+    /* realisation 0 of the WHOLE ensemble is the one the reference drops (:800-802,:817): a shard that does not
+     * start at realisation 0 (real_offset != 0) averages its own realisations plainly */
+    const int quirk = (P->mean_quirk != 0 && P->real_offset == 0) ? 1 : 0;
+    orc_masked_mean_f32(xr, acc, R, S, quirk, mean, &count);
     /* :237-239  f = -U0[0]*U0[1..S] - UT + U0[0]*T, in fp64 */
     for (uint32_t m = 0; m < S; ++m)
         f[m] = (-U0[0] * U0[m + 1] - (double)mean[m]) + U0[0] * (double)P->time_horizon;
     if (dsums) {
+        /* the partial block of a shard, 2S+1 doubles: [sum_m over the accepted realisations -- without realisation 0
+         * when the reference's rule applies | accepted count | x0_m = restricted position of realisation 0 (0 when
+         * the rule does not apply)].  Blocks of several shards add element-wise; orc_edm_residual_from_sums applies
+         * the "count == 1 re-includes realisation 0" rule to the total. */
         for (uint32_t m = 0; m < S; ++m) {
             double a = 0.0;
             for (uint32_t r = 0; r < R; ++r) {
-                uint32_t flag = acc[r];
-                if (P->mean_quirk && r == 0) flag = count;
-                if (flag == 1u) a += (double)xr[(size_t)m * R + r];
+                if (quirk && r == 0) continue;
+                if (acc[r] == 1u) a += (double)xr[(size_t)m * R + r];
             }
             dsums[m] = a;
+            dsums[S + 1 + m] = quirk ? (double)xr[(size_t)m * R] : 0.0;
         }
         dsums[S] = (double)count;
     }
@@ -465,11 +472,27 @@ void orc_edm_math_probe(int op, const float* a, const float* b, float* out, size
     }
 }
 
+/* f from the element-wise sum of the shards' partial blocks (see orc_edm_compute_f): the averaging rule applied to
+ * the totals, one rounding to fp32, then EventDrivenMap.cu:237-239 in fp64 */
+void orc_edm_residual_from_sums(const orc_edm_params* P, const double* Z, const double* sc, double* f)
+{
+    const uint32_t S = P->n_spikes;
+    double U0[ORC_MAX_SPIKES + 1];
+    U0[0] = Z[0]; U0[1] = 0.0;
+    for (uint32_t i = 2; i <= S; ++i) U0[i] = Z[i - 1];
+    const double count = sc[S];
+    for (uint32_t m = 0; m < S; ++m) {
+        const double s = sc[m] + ((P->mean_quirk != 0 && count == 1.0) ? sc[S + 1 + m] : 0.0);
+        const float mean = (float)(s / count);
+        f[m] = (-U0[0] * U0[m + 1] - (double)mean) + U0[0] * (double)P->time_horizon;
+    }
+}
+
 void orc_edm_default_params(orc_edm_params* p)
 {
     /* parameters.hpp:1-15, Driver.cu:16,19 ; counterMax := 100 (undefined upstream) */
     p->vth = 1.0f; p->a1 = 11.0f; p->a2 = 7.0f; p->b1 = 5.0f; p->b2 = 3.5f; p->I = 0.9f; p->L = 3.0f;
     p->newton_tol = 1e-6; p->newton_max_iter = 100; p->n_spikes = 3; p->time_horizon = 5.0f;
     p->n_grid = 1024; p->n_real = 1000; p->beta_mean = 13.0589f; p->beta_stddev = 0.0f;
-    p->seed = 0x5EED0005ull; p->math_mode = 0; p->mean_quirk = 0; p->max_events = 1u << 20; p->real_offset = 0;
+    p->seed = 0x5EED0005ull; p->math_mode = 0; p->mean_quirk = 1; p->max_events = 1u << 20; p->real_offset = 0;
 }

@@ -335,15 +335,19 @@ void orc_restrict_f32(const float* t0, const uint16_t* i0, const float* t1, cons
  * Documented decisions:
  *   - the reference overwrites accept[0] with the count before the mean reads
  *     the flags (:800-802 vs :817), so realisation 0 is dropped from the sum
- *     unless count == 1.  That is a latent bug, not a specification: here the
- *     flags are left untouched and every accepted realisation is summed.
- *     `quirk != 0` reproduces the reference's behaviour for comparison.
+ *     -- while still counted in the divisor (:822) -- unless count == 1, when
+ *     it is summed whatever its own flag was.  `quirk != 0` reproduces exactly
+ *     that (it is what mi_edm_params.mean_quirk = 1, the default of the
+ *     EventDrivenMap pipeline, selects: results identical to the reference's
+ *     come first); `quirk == 0` leaves the flags untouched and sums every
+ *     accepted realisation (the true mean).
  *   - the reference accumulates in fp32 in a launch-shape-dependent order
  *     (strided partials + shuffle tree); the sum here is accumulated in fp64
  *     in index order, divided by the count in fp64 and rounded to fp32 ONCE
  *     (the reference divides two fp32 values, :822).  Rounding once makes the
- *     mean of identical realisations equal to the common value for every R,
- *     so a residual sharded over GPUs equals the unsharded one when sigma = 0.
+ *     mean of identical realisations a function of the common value and R
+ *     only, so a residual sharded over GPUs equals the unsharded one when
+ *     sigma = 0.
  *     The HIP path produces the same fp64 sum bit-for-bit only when its
  *     partial sums are exact; tests therefore compare the mean with a
  *     1-ulp(fp32) tolerance and the count exactly.

@@ -191,6 +191,8 @@ def _edm_lib():
         L.orc_edm_event_time.restype = C.c_float
         L.orc_edm_beta.argtypes = [pp, C.c_uint32, C.c_uint32]
         L.orc_edm_beta.restype = C.c_float
+        L.orc_edm_residual_from_sums.argtypes = [pp, _f64p, _f64p, _f64p]
+        L.orc_edm_residual_from_sums.restype = None
         L._edm_ready = True
     return L
 
@@ -238,6 +240,13 @@ def edm_beta(p, r, i):
     return float(_edm_lib().orc_edm_beta(C.byref(p), int(r), int(i)))
 
 
+def edm_residual_from_sums(p, Z, sums):
+    """f from the element-wise sum of the shards' partial blocks (2S+1 doubles)."""
+    f = np.empty(p.n_spikes, dtype=np.float64)
+    _edm_lib().orc_edm_residual_from_sums(C.byref(p), _c64(Z), _c64(sums), f)
+    return f
+
+
 def edm_compute_f(p, Z, seed_ind=None, nthreads=1, debug=True):
     """Whole residual.  Returns (f, dbg) with dbg holding every stage output."""
     Z = _c64(Z)
@@ -249,7 +258,7 @@ def edm_compute_f(p, Z, seed_ind=None, nthreads=1, debug=True):
         "t0": np.empty(S * R, np.float32), "i0": np.empty(S * R, np.uint16),
         "t1": np.empty(S * R, np.float32), "i1": np.empty(S * R, np.uint16),
         "accept": np.empty(R, np.uint32), "restricted": np.empty(S * R, np.float32),
-        "sums": np.empty(S + 1, np.float64),
+        "sums": np.empty(2 * S + 1, np.float64),        # partial block [sums | count | x0]
     }
     order = ["v", "s", "w", "t0", "i0", "t1", "i1", "accept", "restricted", "sums"]
     ptrs = [C.c_void_p(dbg[k].ctypes.data) if debug else None for k in order]

@@ -465,6 +465,7 @@ float run3(const char* name, const double* y, int n, const double* xq, double* y
     printf("\n");
     return ts[ts.size() / 2];
 }
+#ifndef EXP_NO_MAIN
 int main(int argc, char** argv) {
     const int n = 1000000; const size_t nq = 100000000 / 65536 * 65536;
     std::vector<double> hy(n + 1); for (int i = 0; i <= n; ++i) hy[i] = sin(6.28 * i / n);
@@ -488,3 +489,4 @@ int main(int argc, char** argv) {
     runp<512, 32, 256, 0, 8, 2>("kp G8 + table prefetch", y, n, xq, yq, nq, 256, ph);
     return 0;
 }
+#endif

@@ -34,10 +34,10 @@ def run(budget, seed, ctx=None):
         p = oracle.edm_default_params(beta_mean=edm.params.beta_mean, n_real=edm.params.n_real, **kw)
         fo, d = oracle.edm_compute_f(p, Z, nthreads=8)
         bad = [k for k in ("seed_ind", "w", "v", "s", "t0", "i0", "t1", "i1", "accept", "restricted") if not np.array_equal(dbg[k], d[k], equal_nan=True)]
-        if bad or partial[-1] != d["sums"][-1] or not np.allclose(f, fo, rtol=0, atol=3e-7, equal_nan=True):
+        if bad or partial[S] != d["sums"][S] or not np.allclose(f, fo, rtol=0, atol=3e-7, equal_nan=True):
             print("MISMATCH", bad, kw, Z, f, fo, flush=True)
             raise AssertionError("differential fuzz mismatch (details printed above)")
-        accepted += int(d["sums"][-1] > 0)
+        accepted += int(d["sums"][S] > 0)
         cases += 1
         edm.close()
     os.environ.pop("MI_EDM_WAVES_PER_REALISATION", None)

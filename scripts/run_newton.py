@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE configs 4-5: EventDrivenMap residual / full Newton solve with realisations sharded over the GPUs of
-one node (one process per GPU; all-reduce of S+1 fp64 scalars per residual evaluation).
+one node (one process per GPU; all-reduce of the 2S+1 fp64 scalars of the partial block per residual evaluation).
 
   python scripts/run_newton.py --real 125000                       # 1 GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts/run_newton.py --real 1000000
@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--residual-only", action="store_true", help="config 4: time ComputeF(Z0) only")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank on cuda:0 (gloo only)")
+    ap.add_argument("--true-mean", action="store_true", help="mean_quirk = 0 (default: the reference's averaging, "
+                    "EventDrivenMap.cu:800-824)")
+    ap.add_argument("--max-iterations", type=int, default=10)
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -47,11 +50,12 @@ def main():
     ctx = mi.Context(local)
     lo, hi = sharding.shard_bounds(a.real, rank, world)
     edm = mi.EventDrivenMap(ctx, [13.0589], hi - lo, n_grid=a.threads, real_offset=lo, beta_stddev=a.sigma,
-                            math_mode=mi.MATH_FAST if a.fast else mi.MATH_EXACT, seed=0x5EED0005)
+                            math_mode=mi.MATH_FAST if a.fast else mi.MATH_EXACT, seed=0x5EED0005,
+                            mean_quirk=0 if a.true_mean else 1)
     ms = []
 
     class Sharded:
-        """ComputeF = local partial sums on this GPU -> all-reduce(sum) of S+1 doubles -> host epilogue."""
+        """ComputeF = local partial sums on this GPU -> all-reduce(sum) of the 2S+1-double partial block -> host epilogue."""
 
         def ComputeF(self, Z):
             t = time.perf_counter()
@@ -75,7 +79,7 @@ def main():
         f = prob.ComputeF(Z0)
         out = {"config": "EventDrivenMap residual eval (BASELINE configs[3])", "f": f.tolist()}
     else:
-        pars = newton.ParameterList(tolerance=1e-4, maxIterations=10, printOutput=(rank == 0), finiteDifferenceEpsilon=1e-2)
+        pars = newton.ParameterList(tolerance=1e-4, maxIterations=a.max_iterations, printOutput=(rank == 0), finiteDifferenceEpsilon=1e-2)
         u, hist, conv, it = newton.NewtonSolver(prob, Z0, pars, printer=lambda s: print(s, file=sys.stderr)).Solve()
         out = {"config": "Full NewtonSolver loop, Driver.cu problem (BASELINE configs[4])", "converged": bool(conv),
                "iterations": it, "solution": u.tolist(), "history": hist, "final_norm": hist[-1]}
@@ -84,7 +88,8 @@ def main():
         out.update({"n_gpus": world, "realisations_total": a.real, "realisations_per_gpu": hi - lo, "grid_points": a.threads,
                     "math": "fast" if a.fast else "exact", "sigma": a.sigma, "wall_s": wall, "compute_f_calls": len(ms),
                     "compute_f_ms_mean": float(np.mean(ms)), "evolve_ms_last": edm.last_timings()["evolve_ms"],
-                    "exchange": "all-reduce(sum) of %d fp64 scalars per ComputeF" % (int(edm.params.n_spikes) + 1)})
+                    "mean": "true" if a.true_mean else "reference",
+                    "exchange": "all-reduce(sum) of %d fp64 scalars per ComputeF" % (2 * int(edm.params.n_spikes) + 1)})
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -52,7 +52,7 @@ int main(void)
     P p;
     orc_edm_default_params(&p);
     p.n_real = 2; p.n_grid = 512; p.beta_stddev = 0.2f;
-    double Z[3] = {0.3310, 0.6914, 1.3557}, f[3], sums[4];
+    double Z[3] = {0.3310, 0.6914, 1.3557}, f[3], sums[7];   /* partial block: 2S+1 */
     uint16_t seed[8] = {0};
     if (orc_edm_compute_f(&p, Z, f, seed, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, sums, 2)) return 2;
     printf("oracle under sanitizers ok: f = %g %g %g\n", f[0], f[1], f[2]);

@@ -16,7 +16,7 @@ HEADER = os.path.join(ROOT, "include", "mi355_interp.h")
 def declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"^\s*(?:mi_status|const char\*|int|void)\s+(mi_[a-z0-9_]+)\s*\(", text, flags=re.M)
+    names = re.findall(r"^\s*(?:mi_status|const char\*|int|void|size_t|mi_ctx\*|mi_edm\*)\s+(mi_[a-z0-9_]+)\s*\(", text, flags=re.M)
     assert len(names) > 25
     return sorted(set(names))
 
@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     lib = ctypes.CDLL(path)
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, "declared in mi355_interp.h but not exported: %s" % missing
-    assert lib.mi_abi_version() == 1
+    assert lib.mi_abi_version() == 2
 
 
 def test_python_binding_table_matches_header():

@@ -65,10 +65,12 @@ def _run(mi_ctx, **kw):
     return edm, f, partial, edm.debug_read()
 
 
-@pytest.mark.parametrize("n_grid,n_real", [(1024, 8), (512, 5), (1000, 3), (64, 4)])
-def test_compute_f_exact_mode_bit_parity(mi_ctx, n_grid, n_real):
-    edm, f, partial, dbg = _run(mi_ctx, n_grid=n_grid, n_real=n_real)
-    p = oracle.edm_default_params(n_grid=n_grid, n_real=n_real)
+@pytest.mark.parametrize("mean_quirk", [1, 0])      # 1 (the default): the reference's averaging; 0: the true mean
+@pytest.mark.parametrize("n_grid,n_real", [(1024, 8), (512, 5), (1000, 3), (64, 4), (1024, 1)])
+def test_compute_f_exact_mode_bit_parity(mi_ctx, n_grid, n_real, mean_quirk):
+    edm, f, partial, dbg = _run(mi_ctx, n_grid=n_grid, n_real=n_real, mean_quirk=mean_quirk)
+    p = oracle.edm_default_params(n_grid=n_grid, n_real=n_real, mean_quirk=mean_quirk)
+    assert edm.params.mean_quirk == mean_quirk and oracle.edm_default_params().mean_quirk == 1
     fo, d = oracle.edm_compute_f(p, Z_DRIVER, nthreads=8)
     assert np.array_equal(dbg["seed_ind"], d["seed_ind"])
     for k in ("w", "v", "s"):
@@ -76,8 +78,14 @@ def test_compute_f_exact_mode_bit_parity(mi_ctx, n_grid, n_real):
     for k in ("t0", "i0", "t1", "i1", "accept"):
         assert np.array_equal(dbg[k], d[k], equal_nan=True), k           # evolve: last / crossed events
     assert np.array_equal(dbg["restricted"], d["restricted"], equal_nan=True)
-    assert partial[-1] == d["sums"][-1]
-    assert np.allclose(partial[:-1], d["sums"][:-1], rtol=1e-12, atol=0, equal_nan=True)
+    S = 3                                                                # partial block [sums | count | x0]
+    assert partial.shape == (2 * S + 1,) and partial[S] == d["sums"][S]
+    assert np.allclose(partial[:S], d["sums"][:S], rtol=1e-12, atol=0, equal_nan=True)
+    assert np.array_equal(partial[S + 1:], d["sums"][S + 1:], equal_nan=True)
+    if mean_quirk:                                                       # realisation 0 travels separately
+        assert np.array_equal(partial[S + 1:], dbg["restricted"].reshape(S, n_real)[:, 0].astype(np.float64), equal_nan=True)
+    else:
+        assert np.all(partial[S + 1:] == 0.0)
     assert np.allclose(f, fo, rtol=0, atol=2e-7, equal_nan=True)         # 1 ulp(fp32) of the mean (sum order)
     # residual recomputed from the partial sums (what a multi-GPU all-reduce feeds) equals the device path
     assert np.allclose(edm.residual_from_sums(Z_DRIVER, partial), f, rtol=0, atol=1e-15, equal_nan=True)
@@ -205,7 +213,7 @@ def test_concurrent_evaluations_equal_sequential_ones(mi_ctx):
     seq = np.stack([edm.ComputeF(z) for z in Zs])
     assert np.array_equal(edm.ComputeFBatch(Zs), seq)
     F, P = edm.ComputeFBatch(Zs[:2], want_partial=True)
-    assert np.array_equal(F, seq[:2]) and P.shape == (2, 4) and np.all(P[:, -1] == P[0, -1])
+    assert np.array_equal(F, seq[:2]) and P.shape == (2, 7) and np.all(P[:, 3] == P[0, 3])
     edm.SetParameterStdDev(0.3)                          # the replicas must pick this up
     seq2 = np.stack([edm.ComputeF(z) for z in Zs[:3]])
     assert not np.array_equal(seq2, seq[:3])
@@ -232,13 +240,67 @@ def test_python_newton_on_gpu_matches_oracle_newton(mi_ctx):
     import armadillocudalinearinterpolation_amd as mi
     from armadillocudalinearinterpolation_amd import newton
     Z0 = [float(np.float32(z)) for z in Z_DRIVER]
-    edm = mi.EventDrivenMap(mi_ctx, [13.0589], 64)
+    edm = mi.EventDrivenMap(mi_ctx, [13.0589], 64, mean_quirk=0)          # the true mean does not depend on R when sigma = 0
     pars = newton.ParameterList(tolerance=1e-4, maxIterations=10, printOutput=False, finiteDifferenceEpsilon=1e-2)
     u, hist, conv, it = newton.NewtonSolver(edm, Z0, pars).Solve()
 
     class Orc:
         def ComputeF(self, Z):
-            return oracle.edm_compute_f(oracle.edm_default_params(n_real=1), Z)[0]
+            return oracle.edm_compute_f(oracle.edm_default_params(n_real=1, mean_quirk=0), Z)[0]
     uo, ho, co, io = newton.NewtonSolver(Orc(), Z0, pars).Solve()
     assert conv and co and it == io
     assert np.allclose(u, uo, rtol=0, atol=1e-4) and np.allclose(hist, ho, rtol=0, atol=5e-6)
+
+
+def _one_realisation_reference(n_grid, Z):
+    """One oracle realisation (sigma = 0: every realisation is this one) and the residual of R copies of it under both
+    averaging rules: reference (R-1 copies summed, R in the divisor; EventDrivenMap.cu:800-802,:817,:822) and true mean.
+    The device sums the fp32 position in fp64 -- exact -- so the expected mean is fl32(k x / R), bit for bit."""
+    p = oracle.edm_default_params(n_grid=n_grid, n_real=1)
+    _, d = oracle.edm_compute_f(p, Z)
+    x = d["restricted"].astype(np.float64)
+    U0 = np.array([Z[0], 0.0, Z[1], Z[2]])
+
+    def f(R, quirk):
+        k = R - 1 if (quirk and R > 1) else R
+        mean = (k * x / R).astype(np.float32).astype(np.float64)
+        return (-U0[0] * U0[1:] - mean) + U0[0] * 5.0
+    return d, x, f
+
+
+@pytest.mark.parametrize("n_grid", [1024, 512])
+def test_reference_mean_at_the_driver_size(mi_ctx, n_grid):
+    """Driver.cu:19 R = 1000, every realisation accepted, the reference's averaging (the default): f must be the
+    oracle's bit for bit, and differ from the true-mean residual by x_m / 1000 (ten Newton tolerances)."""
+    d, x, fref = _one_realisation_reference(n_grid, Z_DRIVER)
+    R = 1000
+    edm, f, partial, dbg = _run(mi_ctx, n_grid=n_grid, n_real=R)
+    assert edm.params.mean_quirk == 1 and np.all(dbg["accept"] == 1) and partial[3] == R
+    assert np.array_equal(dbg["restricted"].reshape(3, R), np.repeat(d["restricted"].reshape(3, 1), R, axis=1))
+    assert np.array_equal(partial[:3], (R - 1) * x) and np.array_equal(partial[4:], x)
+    assert np.array_equal(f, fref(R, True))
+    _, ft, pt, _ = _run(mi_ctx, n_grid=n_grid, n_real=R, mean_quirk=0)
+    assert np.array_equal(ft, fref(R, False)) and np.array_equal(pt[:3], R * x) and np.all(pt[4:] == 0)
+    assert np.allclose(f - ft, x / R, rtol=0, atol=2e-7) and np.all(np.abs(f - ft) > 5e-4)
+
+
+@pytest.mark.timeout(600)
+def test_config4_per_gpu_share_125k_realisations(mi_ctx):
+    """BASELINE configs[3] at one GPU's share: 125 000 realisations x 1024 grid points, EXACT math, sigma = 0.  Every
+    row must equal row 0, row 0 must equal the oracle's realisation, count == R, and f must be the oracle's for both
+    averaging rules (bit for bit: the sums are exact)."""
+    R = 125_000
+    d, x, fref = _one_realisation_reference(1024, Z_DRIVER)
+    edm, f, partial, dbg = _run(mi_ctx, n_grid=1024, n_real=R)
+    for k in ("t0", "i0", "t1", "i1"):
+        a = dbg[k].reshape(3, R)
+        assert np.all(a == a[:, :1]), k
+        assert np.array_equal(a[:, 0], d[k].reshape(3, 1)[:, 0]), k
+    assert np.all(dbg["accept"] == 1) and partial[3] == R
+    assert np.array_equal(dbg["restricted"].reshape(3, R)[:, 0], d["restricted"])
+    assert np.array_equal(partial[:3], (R - 1) * x) and np.array_equal(f, fref(R, True))
+    edm.params.mean_quirk = 0
+    edm._push()
+    ft, pt = edm.ComputeF(Z_DRIVER, want_partial=True)
+    assert np.array_equal(ft, fref(R, False)) and np.array_equal(pt[:3], R * x) and pt[3] == R
+    edm.close()

@@ -69,7 +69,7 @@ def test_lift_profile_shape():
 def test_residual_is_small_at_the_drivers_initial_guess():
     """The reference's Newton solve starts from Z_DRIVER (Driver.cu:24) because it is near a root: a faithful
     restatement of lift/evolve/restrict must give |F| << 1 there, and every realisation must be accepted."""
-    p = oracle.edm_default_params(n_real=2)
+    p = oracle.edm_default_params(n_real=2, mean_quirk=0)       # the true mean: the physics check
     f, d = oracle.edm_compute_f(p, Z_DRIVER, nthreads=2)
     assert np.all(d["accept"] == 1)
     assert np.linalg.norm(f) < 2e-2
@@ -85,6 +85,41 @@ def test_residual_is_small_at_the_drivers_initial_guess():
     c = Z_DRIVER[0]
     fexp = -c * np.array([0.0, Z_DRIVER[1], Z_DRIVER[2]]) - mean.astype(np.float32).astype(np.float64) + c * 5.0
     assert np.allclose(f, fexp, rtol=0, atol=1e-7)
+    assert np.all(d["sums"][4:] == 0.0)                          # no realisation-0 term without the reference rule
+
+
+def test_reference_averaging_is_the_default_and_leaves_realisation_0_out():
+    """EventDrivenMap.cu:800-802 overwrites accept[0] with the count, :817 then tests accept[index]==1 and :822 divides
+    by accept[0]: with R accepted, identical realisations the reference returns x*(R-1)/R.  That is the default
+    (mean_quirk = 1); the partial block carries realisation 0 separately so that shards can be added."""
+    assert oracle.edm_default_params().mean_quirk == 1
+    R = 4
+    pq = oracle.edm_default_params(n_real=R)
+    pt = oracle.edm_default_params(n_real=R, mean_quirk=0)
+    fq, dq = oracle.edm_compute_f(pq, Z_DRIVER, nthreads=2)
+    ft, dt = oracle.edm_compute_f(pt, Z_DRIVER, nthreads=2)
+    x = dq["restricted"].reshape(3, R)
+    assert np.array_equal(dq["restricted"], dt["restricted"]) and np.all(dq["accept"] == 1)
+    assert dq["sums"][3] == R and np.array_equal(dq["sums"][4:], x[:, 0].astype(np.float64))
+    assert np.array_equal(dq["sums"][:3], x[:, 1:].astype(np.float64).sum(axis=1))
+    mean_q = (dq["sums"][:3] / R).astype(np.float32).astype(np.float64)
+    c = Z_DRIVER[0]
+    assert np.array_equal(fq, (-c * np.array([0.0, Z_DRIVER[1], Z_DRIVER[2]]) - mean_q) + c * 5.0)
+    assert np.allclose(ft - fq, -x[:, 0] / R, rtol=0, atol=1e-6)      # the reference's mean is short by x_0 / R
+    assert np.array_equal(oracle.edm_residual_from_sums(pq, Z_DRIVER, dq["sums"]), fq)
+    # count == 1: realisation 0 is summed whatever its flag (accept[0] then holds 1)
+    p1 = oracle.edm_default_params(n_real=1)
+    f1, d1 = oracle.edm_compute_f(p1, Z_DRIVER)
+    assert np.array_equal(f1, oracle.edm_compute_f(oracle.edm_default_params(n_real=1, mean_quirk=0), Z_DRIVER)[0])
+    assert np.array_equal(oracle.edm_residual_from_sums(p1, Z_DRIVER, d1["sums"]), f1)
+    # shards: blocks add; only the shard holding realisation 0 applies the rule
+    ph = oracle.edm_default_params(n_real=5, beta_stddev=0.3, seed=99)
+    fw, dw = oracle.edm_compute_f(ph, Z_DRIVER, nthreads=2)
+    tot = np.zeros(7)
+    for lo, hi in ((0, 2), (2, 5)):
+        tot += oracle.edm_compute_f(oracle.edm_default_params(n_real=hi - lo, real_offset=lo, beta_stddev=0.3, seed=99), Z_DRIVER)[1]["sums"]
+    assert np.allclose(tot, dw["sums"], rtol=1e-15, atol=0)
+    assert np.allclose(oracle.edm_residual_from_sums(ph, Z_DRIVER, tot), fw, rtol=0, atol=1e-7)
 
 
 def test_heterogeneous_beta_is_deterministic_and_centred():

@@ -103,25 +103,54 @@ def test_arma_wrappers_match_oracle(tmp_path):
     assert np.nanmax(np.abs(got - ref2)) < 1e-14
 
 
-def _newton_on_oracle(p, Z0, tol, max_it, eps, damping=1.0):
+def _oracle_f(p, u, seed_ind=None, n_real_reference_mean=0):
+    """Oracle residual.  n_real_reference_mean = R > 0: the residual of R IDENTICAL realisations (sigma = 0) averaged
+    as the reference does (realisation 0 left out of the sum, R in the divisor, EventDrivenMap.cu:800-802,:817,:822),
+    formed from ONE oracle realisation: the device adds R-1 copies of the fp32 position x in fp64 -- exact, x has 24
+    significant bits and R < 2^29 -- so the mean is fl32((R-1) x / R) (the shortcut is checked against the full oracle
+    at R = 5 in test_reference_mean_shortcut_equals_full_oracle)."""
+    if not n_real_reference_mean:
+        f, d = oracle.edm_compute_f(p, u, seed_ind=seed_ind, nthreads=8, debug=True)
+        return f, d["seed_ind"]
+    R = int(n_real_reference_mean)
+    assert p.beta_stddev == 0.0 and p.n_real == 1
+    _, d = oracle.edm_compute_f(p, u, seed_ind=seed_ind, debug=True)
+    S = p.n_spikes
+    x = d["restricted"].reshape(S, 1)[:, 0].astype(np.float64)
+    if int(d["accept"][0]) != 1:
+        mean = np.full(S, np.nan)                                   # 0 / 0, as on the device
+    elif R == 1:
+        mean = x
+    else:
+        mean = ((R - 1) * x / R).astype(np.float32).astype(np.float64)
+    U0 = np.concatenate([[u[0], 0.0], np.asarray(u, dtype=np.float64)[1:]])
+    f = (-U0[0] * U0[1:S + 1] - mean) + U0[0] * float(p.time_horizon)
+    return f, d["seed_ind"]
+
+
+def test_reference_mean_shortcut_equals_full_oracle():
+    Z = [0.3310, 0.6914, 1.3557]
+    full, _ = oracle.edm_compute_f(oracle.edm_default_params(n_grid=512, n_real=5), Z, nthreads=5)
+    short, _ = _oracle_f(oracle.edm_default_params(n_grid=512, n_real=1), np.array(Z), n_real_reference_mean=5)
+    assert np.array_equal(full, short)
+
+
+def _newton_on_oracle(p, Z0, tol, max_it, eps, damping=1.0, n_real_reference_mean=0):
     """tests-only restatement of NewtonSolver.cpp:40-197 driving the ORACLE residual"""
     u = np.array(Z0, dtype=np.float64)
-    seed = None
-    f, d = oracle.edm_compute_f(p, u, seed_ind=seed, nthreads=8, debug=True)
-    seed = d["seed_ind"]
+    kw = dict(n_real_reference_mean=n_real_reference_mean)
+    f, seed = _oracle_f(p, u, None, **kw)
     hist, it = [np.linalg.norm(f)], 0
     while it < max_it and not hist[-1] <= tol:
         J = np.empty((3, 3))
         for i in range(3):
             du = u.copy()
             du[i] += eps
-            df, d = oracle.edm_compute_f(p, du, seed_ind=seed, nthreads=8)
-            seed = d["seed_ind"]
+            df, seed = _oracle_f(p, du, seed, **kw)
             J[:, i] = (df - f) * eps ** -1
         u = u + damping * np.linalg.solve(J, -f)
         it += 1
-        f, d = oracle.edm_compute_f(p, u, seed_ind=seed, nthreads=8)
-        seed = d["seed_ind"]
+        f, seed = _oracle_f(p, u, seed, **kw)
         hist.append(np.linalg.norm(f))
     return u, hist, it
 
@@ -137,19 +166,43 @@ def test_driver_newton_solve_matches_oracle_newton(tmp_path):
     not-converged exit flag at 512 points."""
     _build()
     Z0 = [float(np.float32(0.3310)), float(np.float32(0.6914)), float(np.float32(1.3557))]
-    # ---- 1024 grid points: converges
+    # ---- 1024 grid points, the reference's averaging (the driver's default; EventDrivenMap.cu:800-824): realisation 0
+    # is left out of the sum and 1000 stays in the divisor, which moves every f_m by x_m / 1000 ~ 1e-3 -- ten times the
+    # Newton tolerance.  The GPU path must follow the oracle's Newton iteration on THAT residual.
+    js = os.path.join(tmp_path, "driver1024ref.json")
+    out = subprocess.run([os.path.join(HOST, "driver"), "--real", "1000", "--threads", "1024", "--json", js],
+                         capture_output=True, text=True)
+    rq = json.load(open(js))
+    assert rq["mean"] == "reference"
+    p1 = oracle.edm_default_params(n_grid=1024, n_real=1)
+    try:
+        uq, histq, itq = _newton_on_oracle(p1, Z0, 1e-4, 10, 1e-2, n_real_reference_mean=1000)
+        okq = bool(histq[-1] <= 1e-4)
+    except np.linalg.LinAlgError:
+        uq, histq, itq, okq = None, [], 0, False
+    assert rq["converged"] == okq and (out.returncode == 0) == okq
+    fq0, _ = _oracle_f(p1, np.array(Z0), n_real_reference_mean=1000)
+    assert np.allclose(rq["f0_1024"], fq0, rtol=0, atol=2e-7)
+    ft0, _ = oracle.edm_compute_f(oracle.edm_default_params(n_grid=1024, n_real=2, mean_quirk=0), Z0)
+    assert np.all(np.abs(np.array(rq["f0_1024"]) - ft0) > 5e-4)              # not the true mean's residual
+    if okq:
+        assert rq["iterations"] == itq
+        assert np.allclose(rq["solution"], uq, rtol=0, atol=1e-4) and np.allclose(rq["history"], histq, rtol=0, atol=5e-6)
+    elif rq["history"] and histq:
+        assert np.allclose(rq["history"][:3], histq[:3], rtol=0, atol=5e-6)
+    # ---- 1024 grid points, the true mean: converges
     js = os.path.join(tmp_path, "driver1024.json")
     out = subprocess.run([os.path.join(HOST, "driver"), "--real", "1000", "--threads", "1024", "--json", js,
-                          "--stability"], capture_output=True, text=True)
+                          "--stability", "--true-mean"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "The method converged after" in out.stdout and "Newton Method" in out.stdout
     r = json.load(open(js))
     assert r["converged"] and r["iterations"] <= 10
     assert r["residual_evaluations"] == 1 + 4 * r["iterations"]
     # sigma = 0: the residual does not depend on the number of realisations, so 2 oracle realisations suffice
-    p = oracle.edm_default_params(n_grid=1024, n_real=2)
+    p = oracle.edm_default_params(n_grid=1024, n_real=2, mean_quirk=0)
     u, hist, it = _newton_on_oracle(p, Z0, 1e-4, 10, 1e-2)
-    assert it == r["iterations"]
+    assert it == r["iterations"] and r["mean"] == "true"
     assert np.allclose(r["solution"], u, rtol=0, atol=1e-4)                 # same root within the Newton tolerance
     assert np.allclose(r["history"], hist, rtol=0, atol=5e-6)
     assert r["history"][-1] <= 1e-4
@@ -172,11 +225,11 @@ def test_driver_newton_solve_matches_oracle_newton(tmp_path):
     js = os.path.join(tmp_path, "driver512.json")
     dbg = os.path.join(tmp_path, "dumps")
     os.makedirs(dbg)
-    out = subprocess.run([os.path.join(HOST, "driver"), "--real", "1000", "--json", js, "--debug", dbg],
+    out = subprocess.run([os.path.join(HOST, "driver"), "--real", "1000", "--json", js, "--debug", dbg, "--true-mean"],
                          capture_output=True, text=True)
     assert out.returncode == 1 and "The method failed" in out.stdout          # not converged, or a NaN/singular Jacobian
     r = json.load(open(js))
-    p = oracle.edm_default_params(n_grid=512, n_real=2)
+    p = oracle.edm_default_params(n_grid=512, n_real=2, mean_quirk=0)
     try:
         u, hist, it = _newton_on_oracle(p, Z0, 1e-4, 10, 1e-2)
         oracle_ok = bool(hist[-1] <= 1e-4)

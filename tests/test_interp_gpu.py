@@ -91,7 +91,12 @@ def test_restrict_and_mean_golden(mi_ctx, golden_dir):
             assert np.all(np.abs(got - g[key]) <= np.spacing(np.abs(g[key]).astype(np.float32)))
         assert int(c.item()) == int(g["count"]) == int(f["count"].item())
         assert np.array_equal(f["restricted"].cpu().numpy(), g["out"])
-        assert np.allclose(f["sums"].cpu().numpy() / int(g["count"]), g[key], rtol=1e-6)
+        blk = f["sums"].cpu().numpy()                                        # partial block [sums | count | x0]
+        assert blk.shape == (7,) and blk[3] == int(g["count"])
+        x0 = blk[4:] if quirk else 0.0                                       # realisation 0 travels separately
+        tot = blk[:3] + (x0 if (quirk and int(g["count"]) == 1) else 0.0)
+        assert np.allclose(tot / int(g["count"]), g[key], rtol=1e-6)
+        assert np.array_equal(blk[4:], g["out"].reshape(3, -1)[:, 0].astype(np.float64) if quirk else np.zeros(3))
     # in-place form of the reference (out aliases lastSpikeTime, EventDrivenMap.cu:783)
     t0c = t0.clone()
     mi.restrict(mi_ctx, t0c, i0, t1, i1, T, L, N, out=t0c)
@@ -515,3 +520,31 @@ def test_restrict_mean_cfg4_size(mi_ctx):
     # run-to-run reproducibility (no float atomics)
     f2 = mi.restrict_mean(mi_ctx, *d, 5.0, 3.0, N, S)
     assert np.array_equal(f["mean"].cpu().numpy(), f2["mean"].cpu().numpy())
+
+
+def test_host_path_error_leaves_nothing_pinned(mi_ctx, monkeypatch):
+    """a failing HIP call inside the chunked, pinned host path must fall through to the stream drain and
+    the un-pinning (MI_TEST_FAIL_HOST_CHUNK injects the failure); afterwards no caller range stays registered, the
+    same arrays work again, and two calls sharing one query array keep it pinned until the last one is done."""
+    import armadillocudalinearinterpolation_amd as mi
+    from armadillocudalinearinterpolation_amd import _lib
+    L = _lib.load()
+    ng, nq = 1000, (17 << 20) + 5                          # > 2 chunks of 8 M: the pinned, pipelined path
+    X = np.arange(ng) / (ng - 1)
+    Y = np.cos(3 * X)
+    grid = mi.Grid1.from_nodes(mi_ctx, X, Y)
+    xi = oracle.splitmix_uniform(77, nq)
+    assert L.mi_debug_pinned_ranges() == 0
+    monkeypatch.setenv("MI_TEST_FAIL_HOST_CHUNK", "1")
+    with pytest.raises(mi.MiError) as e:
+        grid.interp_host(xi)
+    assert "MI_TEST_FAIL_HOST_CHUNK" in str(e.value) and L.mi_debug_pinned_ranges() == 0
+    g2 = mi.Grid2.uniform(mi_ctx, 0.0, 0.5, 3, 0.0, 0.5, 3, np.arange(9.0).reshape(3, 3))
+    with pytest.raises(mi.MiError):
+        g2.interp_host(xi, xi)
+    assert L.mi_debug_pinned_ranges() == 0
+    monkeypatch.delenv("MI_TEST_FAIL_HOST_CHUNK")
+    got = grid.interp_host(xi)
+    assert L.mi_debug_pinned_ranges() == 0
+    idx = np.arange(0, nq, 4099)
+    assert np.array_equal(got[idx], oracle.interp1_bracket(X, Y, xi[idx]))
