@@ -26,6 +26,17 @@ def _deps():
     return sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(REPO_ROOT, "include", "*.h"))
 
 
+def source_hash():
+    """sha256 over the device / ABI sources the library is built from (sorted paths, contents only): what a committed
+    profile is stamped with, so that bench.py can tell whether a measured traffic figure belongs to the running build."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(_deps()):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
 def is_stale():
     if not os.path.exists(LIB_PATH):
         return True

@@ -9,6 +9,7 @@ realisations / spikes for EventDrivenMap (EventDrivenMap.hpp:11-121).
 """
 import ctypes as C
 import math
+import weakref
 
 import numpy as np
 
@@ -49,6 +50,7 @@ class Context:
         check(self._L.mi_ctx_create(int(device), C.byref(h)))
         self._h = h
         self.device = int(device)
+        self._children = weakref.WeakSet()     # grids / problems created on this context: closed before it is
         if stream == "torch":
             self.use_torch_stream()
         elif stream is not None:
@@ -82,6 +84,12 @@ class Context:
         return Timer(self)
 
     def close(self):
+        """Closes the handles created on this context first (their device state belongs to it), then the context."""
+        for child in list(getattr(self, "_children", ()) or ()):
+            try:
+                child.close()
+            except Exception:
+                pass
         if getattr(self, "_h", None):
             self._L.mi_ctx_destroy(self._h)
             self._h = None
@@ -128,6 +136,8 @@ class Grid1:
 
     def __init__(self, ctx, handle):
         self._ctx, self._h, self._L = ctx, handle, ctx._L
+        if hasattr(ctx, "_children"):
+            ctx._children.add(self)
 
     @classmethod
     def from_nodes(cls, ctx, x, y, sanitise=True):
@@ -212,6 +222,8 @@ class Grid2:
 
     def __init__(self, ctx, handle):
         self._ctx, self._h, self._L = ctx, handle, ctx._L
+        if hasattr(ctx, "_children"):
+            ctx._children.add(self)
 
     @staticmethod
     def _colmajor(z, ny, nx):
@@ -340,6 +352,8 @@ class EventDrivenMap:
         h = C.c_void_p()
         check(self._L.mi_edm_create(ctx._h, C.byref(self.params), C.byref(h)), ctx._h)
         self._h = h
+        if hasattr(ctx, "_children"):
+            ctx._children.add(self)
 
     def _push(self):
         check(self._L.mi_edm_set_params(self._h, C.byref(self.params)), self._ctx._h)
@@ -428,9 +442,19 @@ class EventDrivenMap:
             if bytes(rep.params) != mine:                      # a setter ran on the parent since the last batch
                 C.memmove(C.byref(rep.params), C.byref(self.params), C.sizeof(EdmParams))
                 rep._push()
-        for rep, z in zip(reps, Zs):
-            rep.begin(z)
-        out = [rep.end(want_partial) for rep in reps[:len(Zs)]]
+        begun = []
+        try:
+            for rep, z in zip(reps, Zs):
+                rep.begin(z)
+                begun.append(rep)
+            out = [rep.end(want_partial) for rep in reps[:len(Zs)]]
+            begun = []
+        finally:
+            for rep in begun:                                  # a begin() or end() raised: nothing may stay pending
+                try:
+                    rep._push()                                # mi_edm_set_params drains the stream and abandons the evaluation
+                except Exception:
+                    pass
         if want_partial:
             return np.stack([o[0] for o in out]), np.stack([o[1] for o in out])
         return np.stack(out)
@@ -466,6 +490,143 @@ class EventDrivenMap:
         self._replicas = []
         if getattr(self, "_h", None):
             self._L.mi_edm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- several GPUs of one node, one host process (mi_group_*) ---------------------------------------------------
+
+def shard_bounds(n, rank, world):
+    """mi_shard_bounds: contiguous balanced split (host arithmetic of the C ABI; equals sharding.shard_bounds)."""
+    lo, hi = C.c_size_t(0), C.c_size_t(0)
+    _lib.load().mi_shard_bounds(int(n), int(rank), int(world), C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+class _GroupCtx:
+    """borrowed view of a group member's context (owned by the group)"""
+
+    def __init__(self, L, h, device):
+        self._L, self._h, self.device = L, h, device
+
+
+class Group:
+    """One process driving several GPUs: devices = [0, 1, ..] (a repeated ordinal rehearses the sharding on one GPU)."""
+    REDUCE_HOST, REDUCE_RCCL = 0, 1
+
+    def __init__(self, devices):
+        self._L = _lib.load()
+        devices = list(range(devices)) if isinstance(devices, int) else [int(d) for d in devices]
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        check(self._L.mi_group_create(len(devices), arr, C.byref(h)))
+        self._h, self.devices = h, devices
+
+    def __len__(self):
+        return int(self._L.mi_group_size(self._h))
+
+    def ctx(self, rank):
+        return _GroupCtx(self._L, C.c_void_p(self._L.mi_group_ctx(self._h, int(rank))), self.devices[rank])
+
+    def set_reduce(self, mode):
+        check(self._L.mi_group_set_reduce(self._h, int(mode)))
+
+    def synchronize(self):
+        check(self._L.mi_group_synchronize(self._h))
+
+    def grid1(self, X, Y, sanitise=True):
+        X, Y = _np64(X), _np64(Y)
+        t = C.c_void_p()
+        check(self._L.mi_group_grid1_create(self._h, _ptr(X), _ptr(Y), X.size, 1 if sanitise else 0, C.byref(t)))
+        return GroupGrid1(self, t)
+
+    def edm(self, parameters, noReal, **overrides):
+        return GroupEventDrivenMap(self, parameters, noReal, **overrides)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mi_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GroupGrid1:
+    def __init__(self, group, h):
+        self._g, self._L, self._h = group, group._L, h
+
+    def interp_host(self, xq, extrap=math.nan):
+        """host arrays in, host array out; the queries are sharded over the group's devices"""
+        xq = _np64(xq)
+        out = np.empty_like(xq)
+        check(self._L.mi_group_interp1_f64_host(self._g._h, self._h, _ptr(xq), _ptr(out), xq.size, float(extrap)))
+        return out
+
+    def interp_dev(self, xq_shards, extrap=math.nan, gather=False):
+        """device-resident shards (one float64 tensor per group member, equal sizes); returns the per-shard results and,
+        with gather=True, one buffer per member holding every shard (RCCL all-gather, or device copies in a rehearsal group)"""
+        torch = _torch()
+        P, n = len(self._g), int(xq_shards[0].numel())
+        assert len(xq_shards) == P and all(int(t.numel()) == n for t in xq_shards)
+        outs = [torch.empty_like(t) for t in xq_shards]
+        full = [torch.empty(P * n, dtype=torch.float64, device=t.device) for t in xq_shards] if gather else None
+        arr = lambda ts: (C.c_void_p * P)(*[t.data_ptr() for t in ts])  # noqa: E731
+        check(self._L.mi_group_interp1_f64_dev(self._g._h, self._h, arr(xq_shards), arr(outs), n, float(extrap),
+                                               arr(full) if gather else None))
+        self._g.synchronize()
+        return (outs, full) if gather else outs
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mi_group_grid1_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GroupEventDrivenMap:
+    """EventDrivenMap with the realisations sharded over a Group; noReal is the total."""
+
+    def __init__(self, group, parameters, noReal, **overrides):
+        self._g, self._L = group, group._L
+        par = np.atleast_1d(np.asarray(parameters, dtype=np.float64))
+        self.params = default_edm_params(beta_mean=float(np.float32(par[0])), n_real=int(noReal), **overrides)
+        h = C.c_void_p()
+        check(self._L.mi_group_edm_create(group._h, C.byref(self.params), C.byref(h)))
+        self._h = h
+
+    def _push(self):
+        check(self._L.mi_group_edm_set_params(self._h, C.byref(self.params)))
+
+    def ComputeF(self, Z, want_partial=False):
+        Z = _np64(Z)
+        S = int(self.params.n_spikes)
+        f = np.empty(S, dtype=np.float64)
+        partial = np.empty(2 * S + 1, dtype=np.float64)
+        check(self._L.mi_group_edm_compute_f(self._h, _ptr(Z), _ptr(f), _ptr(partial)))
+        return (f, partial) if want_partial else f
+
+    def shard_bounds(self, rank):
+        lo, hi = C.c_size_t(0), C.c_size_t(0)
+        check(self._L.mi_group_edm_shard_bounds(self._h, int(rank), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mi_group_edm_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -510,6 +510,8 @@ struct mi_edm {
     size_t alloc_real = 0;
     bool w_valid = false;
     bool have_run = false;
+    int device = 0;                    // copied from the context at creation (destroy must not dereference the context)
+    hipStream_t pending_stream = nullptr;   // stream of the evaluation in flight
     bool pending = false;              // mi_edm_compute_f_begin has enqueued an evaluation, _end has not collected it
     double pending_U0[kMaxSpikes + 1] = {0};
     uint16_t seed_ind[kMaxSpikes] = {0};
@@ -757,6 +759,7 @@ mi_status mi_edm_create(mi_ctx* ctx, const mi_edm_params* p, mi_edm** out)
     mi_edm* e = new (std::nothrow) mi_edm();
     if (!e) return mi::fail(ctx, MI_ERR_NOMEM, "mi_edm_create: out of host memory");
     e->ctx = ctx;
+    e->device = ctx->device;
     e->p = *p;
     fill_model(e->p, &e->M);
     hipError_t err = hipSuccess;
@@ -780,8 +783,10 @@ mi_status mi_edm_create(mi_ctx* ctx, const mi_edm_params* p, mi_edm** out)
 mi_status mi_edm_destroy(mi_edm* e)
 {
     if (!e) return MI_OK;
-    (void)hipSetDevice(e->ctx->device);
-    if (e->pending) (void)hipStreamSynchronize(e->ctx->stream);   // an evaluation begun and never collected still uses the buffers
+    (void)hipSetDevice(e->device);
+    // an evaluation begun and never collected still uses the buffers; the stream it was enqueued on is remembered here
+    // (the context itself may already be gone: the Python layer closes handles in arbitrary order at interpreter exit)
+    if (e->pending) (void)hipStreamSynchronize(e->pending_stream);
     free_real_buffers(e);
     void* bufs[] = {e->d_v, e->d_s, e->d_w, e->d_result, e->d_one};
     for (void* b : bufs)
@@ -829,9 +834,16 @@ mi_status mi_edm_compute_f_begin(mi_edm* e, const double* z)
     for (uint32_t i = 0; i <= S; ++i) sd.U[i] = (float)U0[i];
     seed_indices(e->p, z, e->seed_ind);
     for (uint32_t m = 0; m < S; ++m) sd.ind[m] = e->seed_ind[m];
-    mi_status st = (e->p.math_mode == MI_EDM_MATH_FAST) ? run_pipeline<1>(e, sd) : run_pipeline<0>(e, sd);
-    if (st != MI_OK) return st;
+    // marked before the first launch: if run_pipeline fails half-way, kernels already enqueued still use the buffers,
+    // and mi_edm_destroy / mi_edm_set_params synchronise only when they see work pending
     e->pending = true;
+    e->pending_stream = ctx->stream;
+    mi_status st = (e->p.math_mode == MI_EDM_MATH_FAST) ? run_pipeline<1>(e, sd) : run_pipeline<0>(e, sd);
+    if (st != MI_OK) {
+        (void)hipStreamSynchronize(ctx->stream);   // abandon the partial evaluation
+        e->pending = false;
+        return st;
+    }
     return MI_OK;
 }
 

@@ -66,6 +66,7 @@ struct G1Dev {
 
 struct mi_grid1 {
     mi_ctx* ctx;
+    int device;          // copied at creation: mi_grid1_destroy must not dereference a context that may be gone
     int mode;
     size_t n;
     size_t table_bytes;
@@ -477,6 +478,7 @@ __global__ __launch_bounds__(kLdsBlock) void interp1_lds_kernel(G1Dev g, const d
 #ifndef MI_SWEEP_DYNAMIC
 #define MI_SWEEP_DYNAMIC 0   // hand the gather chunks out dynamically: measured 0.711-0.716 vs 0.707-0.716 ms static -- no gain, off
 #endif
+constexpr size_t kSweepMinTilesPerCu = 2;   // profiles/r02_strong_scaling_shards.log: at 3 tiles per CU (1.25e7 queries) the sweep still wins 0.097 vs 0.135 ms
 constexpr int kSweepThreads = MI_SWEEP_THREADS;
 constexpr int kSweepK = MI_SWEEP_K;                       // queries per lane per tile
 constexpr int kSweepTile = kSweepThreads * kSweepK;       // queries per tile (8 B of LDS each)
@@ -489,7 +491,9 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
 {
     __shared__ double sq[kSweepTile];
     __shared__ unsigned hist[kSweepBins];
+#if MI_SWEEP_DYNAMIC
     __shared__ unsigned next_chunk;          // gather phase: chunks of 256 sorted positions handed out to the waves
+#endif
     const int tid = threadIdx.x;
     if (*order_flag != 0) return;            // queries already ordered locally: the streaming kernel does the work
     // The last workgroup has the fewest tiles: it also probes the query order for the next call (one wave, while
@@ -508,7 +512,9 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
             q[2 * u + 1] = v.y;
         }
         for (int b = tid; b < kSweepBins; b += kSweepThreads) hist[b] = 0;
+#if MI_SWEEP_DYNAMIC
         if (tid == 0) next_chunk = 0;
+#endif
         __syncthreads();
         unsigned short bin[kSweepK], rank[kSweepK];
 #pragma unroll
@@ -975,8 +981,11 @@ mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, size_t table_bytes, const dou
     bool size_ok = table_bytes >= ((size_t)5 << 20);
     if (MODE == 3) size_ok = table_bytes > kLdsMaxTableBytes && !(table_bytes > 2600000 && table_bytes < 3900000);
     if (const char* env = getenv("MI_SWEEP_MIN_BYTES")) size_ok = table_bytes >= (size_t)strtoull(env, nullptr, 10);   // tuning hook
+    // enough tiles for every CU to run a few sweeps (MI_SWEEP_MIN_TILES_PER_CU: tuning hook behind kSweepMinTilesPerCu,
+    // profiles/r02_strong_scaling_shards.log)
+    static const size_t min_tiles_per_cu = [] { const char* e = getenv("MI_SWEEP_MIN_TILES_PER_CU"); return e ? (size_t)strtoull(e, nullptr, 10) : kSweepMinTilesPerCu; }();
     const bool sweep_ok = ctx->query_order != MI_QUERIES_ORDERED && size_ok &&
-                          ntiles >= (size_t)cus * 4 && std::isfinite(d.xmax - d.xmin) && (d.xmax - d.xmin) > 0.0;
+                          ntiles >= (size_t)cus * min_tiles_per_cu && std::isfinite(d.xmax - d.xmin) && (d.xmax - d.xmin) > 0.0;
     if constexpr (MODE == 0 || MODE == 3) {
         // Whole table in LDS: unordered queries over a table that outgrows L1 (32 KiB) but fits LDS (128 KiB).
         // scripts/gpu_small_table_timing.py, 1e8 queries: random 0.516 -> 0.287 ms at 10-16 K nodes; sorted queries are
@@ -1113,6 +1122,7 @@ mi_status build_explicit(mi_ctx* ctx, const std::vector<double>& xs, const std::
     mi_grid1* g = new (std::nothrow) mi_grid1();
     if (!g) return mi::fail(ctx, MI_ERR_NOMEM, "mi_grid1_create: out of host memory");
     g->ctx = ctx;
+    g->device = ctx->device;
     g->n = n;
     g->dev_nodes = g->dev_s = nullptr;
     {   // linspace-like explicit grid: keep only Y, recompute X in registers (bit-exact by construction)
@@ -1327,6 +1337,7 @@ mi_status mi_grid1_create_uniform(mi_ctx* ctx, double x0, double dx, const doubl
     mi_grid1* g = new (std::nothrow) mi_grid1();
     if (!g) return mi::fail(ctx, MI_ERR_NOMEM, "mi_grid1_create_uniform: out of host memory");
     g->ctx = ctx;
+    g->device = ctx->device;
     g->mode = 0;
     g->n = n;
     g->dev_s = nullptr;
@@ -1349,7 +1360,7 @@ mi_status mi_grid1_create_uniform(mi_ctx* ctx, double x0, double dx, const doubl
 mi_status mi_grid1_destroy(mi_grid1* g)
 {
     if (!g) return MI_OK;
-    (void)hipSetDevice(g->ctx->device);
+    (void)hipSetDevice(g->device);
     if (g->dev_nodes) (void)hipFree(g->dev_nodes);
     if (g->dev_s) (void)hipFree(g->dev_s);
     delete g;

@@ -39,6 +39,7 @@ struct G2Dev {
 
 struct mi_grid2 {
     mi_ctx* ctx;
+    int device;            // copied at creation: destroy must not dereference a context that may be gone
     void* dev_x;
     void* dev_y;
     void* dev_z;
@@ -287,6 +288,7 @@ mi_status mi_grid2_create(mi_ctx* ctx, const double* x, size_t nx, const double*
     mi_grid2* g = new (std::nothrow) mi_grid2();
     if (!g) return mi::fail(ctx, MI_ERR_NOMEM, "mi_grid2_create: out of host memory");
     g->ctx = ctx;
+    g->device = ctx->device;
     g->dev_x = g->dev_y = g->dev_z = nullptr;
     st = make_explicit_axis(ctx, xs, "X", &g->dev_x, &g->d.ax);
     if (st == MI_OK) st = make_explicit_axis(ctx, ys, "Y", &g->dev_y, &g->d.ay);
@@ -311,6 +313,7 @@ mi_status mi_grid2_create_uniform(mi_ctx* ctx, double x0, double dx, size_t nx, 
     mi_grid2* g = new (std::nothrow) mi_grid2();
     if (!g) return mi::fail(ctx, MI_ERR_NOMEM, "mi_grid2_create_uniform: out of host memory");
     g->ctx = ctx;
+    g->device = ctx->device;
     g->dev_x = g->dev_y = g->dev_z = nullptr;
     mi_status st = make_uniform_axis(ctx, x0, dx, nx, "x", &g->d.ax);
     if (st == MI_OK) st = make_uniform_axis(ctx, y0, dy, ny, "y", &g->d.ay);
@@ -325,7 +328,7 @@ mi_status mi_grid2_create_uniform(mi_ctx* ctx, double x0, double dx, size_t nx, 
 
 mi_status mi_grid2_destroy(mi_grid2* g)
 {
-    if (g) (void)hipSetDevice(g->ctx->device);
+    if (g) (void)hipSetDevice(g->device);
     destroy(g);
     return MI_OK;
 }

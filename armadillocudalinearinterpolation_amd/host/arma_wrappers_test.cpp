@@ -32,6 +32,17 @@ int main(int argc, char** argv)
     table(XI, YB, -1.0);
     dump(out + "/w_table_nan.bin", YA);
     dump(out + "/w_table_extrap.bin", YB);
+    {   // the same call with the queries sharded over a device group: three shards rehearsed on GPU 0, and GPUs 0..0
+        mi355::DeviceGroup grp(std::vector<int>{0, 0, 0});
+        mi355::GroupInterp1Table gtab(grp, X, Y);
+        arma::vec YG;
+        gtab(XI, YG);
+        dump(out + "/w_group_table.bin", YG);
+        mi355::DeviceGroup one(1);
+        mi355::GroupInterp1Table gone(one, X, Y);
+        gone(XI, YG, -1.0);
+        dump(out + "/w_group1_table_extrap.bin", YG);
+    }
     // bilinear: Z is Y.n_elem x X.n_elem (arma::mat, column-major)
     const arma::uword nx = 40, ny = 25, n2 = 20000;
     arma::vec xg(nx), yg(ny), xq(n2), yq(n2), ZI;

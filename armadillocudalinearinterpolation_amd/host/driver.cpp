@@ -1,7 +1,9 @@
 // The reference's fixed problem (Driver.cu:11-126) on the MI355X path: beta = 13.0589, Z0 = (0.3310, 0.6914,
 // 1.3557), Newton tolerance 1e-4, max 10 iterations, forward-difference epsilon 1e-2, damping 1, 512 grid points.
 //   driver [--real R] [--threads N] [--fast] [--dedup] [--debug DIR] [--json FILE] [--quiet] [--stability]
-//          [--reference-mean | --true-mean]
+//          [--reference-mean | --true-mean] [--gpus N | --devices a,b,..]
+// --gpus N shards the realisations over GPUs 0..N-1 of the node (mi_group_edm_*: one ComputeF per residual, partial
+// sums added across the GPUs); --devices takes explicit ordinals, repeats allowed (0,0 rehearses two shards on one GPU).
 // --reference-mean (the default) averages over realisations exactly as EventDrivenMap.cu:800-824 does (realisation 0
 // left out of the sum, full count in the divisor); --true-mean sums every accepted realisation.
 #include <chrono>
@@ -10,6 +12,7 @@
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "event_driven_map.hpp"
 #include "newton_solver.hpp"
@@ -21,6 +24,7 @@ int main(int argc, char* argv[])
     int noThreads = 512;               // Driver.cu:69
     bool fast = false, quiet = false, stability = false, dedup = false, reference_mean = true;
     const char *debug_dir = nullptr, *json = nullptr;
+    std::vector<int> devices;          // empty: the reference's single device
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--real") && i + 1 < argc) noReal = std::strtoul(argv[++i], nullptr, 10);
         else if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) noThreads = std::atoi(argv[++i]);
@@ -29,6 +33,11 @@ int main(int argc, char* argv[])
         else if (!std::strcmp(argv[i], "--quiet")) quiet = true;
         else if (!std::strcmp(argv[i], "--reference-mean")) reference_mean = true;
         else if (!std::strcmp(argv[i], "--true-mean")) reference_mean = false;
+        else if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) { const int n = std::atoi(argv[++i]); devices.clear(); for (int d = 0; d < n; ++d) devices.push_back(d); }
+        else if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) {
+            devices.clear();
+            for (char* tok = std::strtok(argv[++i], ","); tok; tok = std::strtok(nullptr, ",")) devices.push_back(std::atoi(tok));
+        }
         else if (!std::strcmp(argv[i], "--stability")) stability = true;
         else if (!std::strcmp(argv[i], "--debug") && i + 1 < argc) debug_dir = argv[++i];
         else if (!std::strcmp(argv[i], "--json") && i + 1 < argc) json = argv[++i];
@@ -37,7 +46,9 @@ int main(int argc, char* argv[])
 
     arma::vec parameters(1);
     parameters(0) = 13.0589f;                                   // Driver.cu:16 (a float literal)
-    EventDrivenMap event(&parameters, noReal);
+    EventDrivenMap* p_event = devices.empty() ? new EventDrivenMap(&parameters, noReal)   // Driver.cu:20
+                                              : new EventDrivenMap(&parameters, noReal, devices);
+    EventDrivenMap& event = *p_event;
     event.SetQuiet(quiet);
     if (fast) event.SetMathMode(MI_EDM_MATH_FAST);
     if (dedup) event.SetDedupIdentical(true);
@@ -94,10 +105,10 @@ int main(int argc, char* argv[])
         FILE* fp = std::fopen(json, "w");
         if (fp) {
             std::fprintf(fp, "{\"converged\": %s, \"iterations\": %d, \"residual_evaluations\": %d, \"n_real\": %u, "
-                             "\"n_grid\": %d, \"math\": \"%s\", \"mean\": \"%s\", \"solve_seconds\": %.6f,\n \"solution\": [%.17g, %.17g, %.17g],\n"
+                             "\"n_grid\": %d, \"math\": \"%s\", \"mean\": \"%s\", \"shards\": %d, \"solve_seconds\": %.6f,\n \"solution\": [%.17g, %.17g, %.17g],\n"
                              " \"f0_1024\": [%.17g, %.17g, %.17g],\n \"history\": [",
                          ok ? "true" : "false", newton.LastIterationCount(), newton.LastResidualEvaluations(), noReal,
-                         noThreads, fast ? "fast" : "exact", reference_mean ? "reference" : "true", secs, solution(0), solution(1), solution(2), f0(0), f0(1), f0(2));
+                         noThreads, fast ? "fast" : "exact", reference_mean ? "reference" : "true", devices.empty() ? 1 : (int)devices.size(), secs, solution(0), solution(1), solution(2), f0(0), f0(1), f0(2));
             const int nh = failure.empty() ? newton.LastIterationCount() + 1 : 0;
             for (int i = 0; i < nh; ++i) std::fprintf(fp, "%s%.17g", i ? ", " : "", history(i));
             std::fprintf(fp, "],\n \"n_unstable\": %d, \"eigenvalues\": [", n_unstable);
@@ -106,5 +117,6 @@ int main(int argc, char* argv[])
             std::fclose(fp);
         }
     }
+    delete p_event;
     return ok ? 0 : 1;
 }

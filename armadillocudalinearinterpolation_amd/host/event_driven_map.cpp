@@ -51,25 +51,52 @@ EventDrivenMap::EventDrivenMap(const arma::vec* pParameters, unsigned int noReal
     partial_.zeros();
 }
 
+EventDrivenMap::EventDrivenMap(const arma::vec* pParameters, unsigned int noReal, const std::vector<int>& devices)
+    : ctx_(nullptr), edm_(nullptr), device_(devices.empty() ? 0 : devices[0])
+{
+    assert(pParameters && pParameters->n_elem >= 1 && !devices.empty());
+    must(mi_group_create(static_cast<int>(devices.size()), devices.data(), &group_), nullptr, "mi_group_create");
+    mi_edm_default_params(&p_);
+    p_.beta_mean = static_cast<float>((*pParameters)[0]);
+    p_.n_real = noReal;
+    const auto now = std::chrono::steady_clock::now().time_since_epoch().count();
+    p_.seed = static_cast<unsigned long long>(now);
+    must(mi_group_edm_create(group_, &p_, &gedm_), nullptr, "mi_group_edm_create");
+    ctx_ = mi_group_ctx(group_, 0);
+    edm_ = mi_group_edm_shard(gedm_, 0);
+    partial_.set_size(MI_EDM_PARTIAL_LEN(p_.n_spikes));
+    partial_.zeros();
+}
+
 EventDrivenMap::~EventDrivenMap()
 {
     for (Replica& r : replicas_) {
         mi_edm_destroy(r.edm);
         mi_ctx_destroy(r.ctx);
     }
+    if (group_) {                         // the group owns the shard handles and contexts
+        mi_group_edm_destroy(gedm_);
+        mi_group_destroy(group_);
+        return;
+    }
     mi_edm_destroy(edm_);
     mi_ctx_destroy(ctx_);
 }
 
-void EventDrivenMap::Push() { must(mi_edm_set_params(edm_, &p_), ctx_, "mi_edm_set_params"); }
+void EventDrivenMap::Push()
+{
+    if (gedm_) must(mi_group_edm_set_params(gedm_, &p_), nullptr, "mi_group_edm_set_params");
+    else must(mi_edm_set_params(edm_, &p_), ctx_, "mi_edm_set_params");
+}
 
 void EventDrivenMap::ComputeF(const arma::vec& u, arma::vec& f)
 {
     assert(u.n_elem == p_.n_spikes);
     f.set_size(p_.n_spikes);
     partial_.set_size(MI_EDM_PARTIAL_LEN(p_.n_spikes));
-    must(mi_edm_compute_f(edm_, u.memptr(), f.memptr(), partial_.memptr()), ctx_, "mi_edm_compute_f");
-    if (debug_) Dump();
+    if (gedm_) must(mi_group_edm_compute_f(gedm_, u.memptr(), f.memptr(), partial_.memptr()), nullptr, "mi_group_edm_compute_f");
+    else must(mi_edm_compute_f(edm_, u.memptr(), f.memptr(), partial_.memptr()), ctx_, "mi_edm_compute_f");
+    if (debug_ && !gedm_) Dump();         // the Save* taps read one device's buffers: single-GPU mode only
 }
 
 void EventDrivenMap::ComputeFBatch(const arma::mat& U, arma::mat& F)
@@ -77,7 +104,8 @@ void EventDrivenMap::ComputeFBatch(const arma::mat& U, arma::mat& F)
     const arma::uword S = p_.n_spikes, B = U.n_cols;
     assert(U.n_rows == S);
     F.set_size(S, B);
-    if (debug_) {                                       // the Save* dumps follow every single evaluation: keep them
+    if (debug_ || gedm_) {                              // the Save* dumps follow every single evaluation: keep them; a
+                                                        // sharded problem already fills every GPU with one evaluation
         arma::vec u(S), f;
         for (arma::uword j = 0; j < B; ++j) {
             for (arma::uword i = 0; i < S; ++i) u(i) = U(i, j);

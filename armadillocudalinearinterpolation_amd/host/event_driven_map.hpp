@@ -14,7 +14,11 @@
 class EventDrivenMap : public AbstractNonlinearProblem, public AbstractBatchedNonlinearProblem {
   public:
     EventDrivenMap(const arma::vec* pParameters, unsigned int noReal, int device = 0);
-    ~EventDrivenMap() override;
+    // the same problem with the realisations sharded over several GPUs of the node (mi_group_edm_*): still ONE
+    // ComputeF per residual (AbstractNonlinearProblem.hpp:11), so NewtonSolver and Driver stay as they are.  A repeated
+    // ordinal (e.g. {0, 0}) rehearses the sharding on a box with fewer GPUs.
+    EventDrivenMap(const arma::vec* pParameters, unsigned int noReal, const std::vector<int>& devices);
+    virtual ~EventDrivenMap();
     EventDrivenMap(const EventDrivenMap&) = delete;              // the reference's copy would double-free
     EventDrivenMap& operator=(const EventDrivenMap&) = delete;
 
@@ -60,6 +64,8 @@ class EventDrivenMap : public AbstractNonlinearProblem, public AbstractBatchedNo
     void Dump();
     mi_ctx* ctx_;
     mi_edm* edm_;
+    mi_group* group_ = nullptr;          // multi-GPU mode: the shards live in gedm_, edm_ / ctx_ alias shard 0 (debug taps)
+    mi_group_edm* gedm_ = nullptr;
     mi_edm_params p_;
     struct Replica { mi_ctx* ctx; mi_edm* edm; mi_edm_params p; };
     std::vector<Replica> replicas_;

@@ -21,12 +21,13 @@ def _lsr(z, k):
     return (z >> k) & ((1 << (64 - k)) - 1)
 
 
-def splitmix_uniform(seed, n, device, chunk=1 << 24):
+def splitmix_uniform(seed, n, device, chunk=1 << 24, offset=0):
+    """elements offset .. offset+n-1 of the stream (offset > 0: a rank's contiguous shard of one global query set)"""
     import torch
     out = torch.empty(n, dtype=torch.float64, device=device)
     for a in range(0, n, chunk):
         b = min(n, a + chunk)
-        i = torch.arange(a + 1, b + 1, dtype=torch.int64, device=device)
+        i = torch.arange(offset + a + 1, offset + b + 1, dtype=torch.int64, device=device)
         z = i * _s64(GOLDEN) + _s64(seed)
         z = (z ^ _lsr(z, 30)) * _s64(C1)
         z = (z ^ _lsr(z, 27)) * _s64(C2)

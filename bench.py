@@ -29,6 +29,7 @@ NG = 1_000_000
 NQ = 100_000_000
 SEED_Q = 0x5EED0003
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+SWEEP_MIN_TILES_PER_CU = int(os.environ.get("MI_SWEEP_MIN_TILES_PER_CU", "2"))   # csrc/mi_interp1.hip kSweepMinTilesPerCu
 
 
 def parse():
@@ -41,12 +42,23 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (sorted queries, "
                     "implicit-uniform table, config 3, restrict+mean, all-gather)")
-    ap.add_argument("--table", choices=["general", "uniform"], default="general")
+    ap.add_argument("--table", choices=["general", "uniform", "nonuniform"], default="general",
+                    help="general: explicit X of configs[1] (detected closed form); uniform: implicit grid; nonuniform: "
+                         "BASELINE.md section 2's jittered grid X_i = (i + 0.5 u_i)/NG, explicit {x,y} table")
     ap.add_argument("--queries", choices=["random", "sorted", "uniform"], default="random")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI, the real thing) or gloo "
                     "(rehearsal of the N>1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--rehearse-one-device", action="store_true",
                     help="map every rank to cuda:0 (only with --dist-backend gloo; timings are then meaningless)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the contract's line): every rank its own --nq queries; strong: ONE set of --nq "
+                         "queries split into contiguous NQ/P shards (BASELINE.md section 2), compute-only and compute + "
+                         "all-gather both reported")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="P",
+                    help="1-GPU rehearsal of the strong-scaling shard sizes: time this GPU on shard 0 of P (NQ/P queries)")
+    ap.add_argument("--config", type=int, choices=[2, 3], default=2,
+                    help="2 (default): BASELINE configs[1], the 1-D headline; 3: configs[2], 4096^2 bilinear, 1e8 scattered "
+                         "queries as the timed workload (for profiling interp2_kernel; same JSON contract)")
     return ap.parse_args()
 
 
@@ -105,13 +117,53 @@ def measured_traffic(mode, queries, nq):
     committed profile does not cover this kernel/configuration."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
+        from armadillocudalinearinterpolation_amd import _build
         t = json.load(open(path))
         e = t.get("interp1_mode%d_%s" % (mode, queries))
         if e and int(e.get("nq", 0)) == int(nq):
-            return e["hbm_bytes_per_launch"]
+            if e.get("source_sha256") != _build.source_hash():
+                return None, "profiles/traffic_latest.json was measured on another build of the kernels (source hash differs): not quoted"
+            return e["hbm_bytes_per_launch"], "rocprofv3 PMC passes of this build (scripts/profile_bench.sh), profiles/traffic_latest.json"
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    return None, "no committed PMC profile covers this configuration"
+
+
+def bench_config3(args, ctx, info, dev, world, rank, barrier, dist):
+    """BASELINE configs[2] as the timed workload: 4096 x 4096 fp64 table (arma::mat layout), 1e8 scattered (x, y) queries per
+    rank (SplitMix64 seed 0x5EED0004), one step = one mi_interp2_f64_dev pass.  Same JSON contract as the headline."""
+    import torch
+
+    import armadillocudalinearinterpolation_amd as mi
+    from armadillocudalinearinterpolation_amd import synth
+    n3, nq = 4096, args.nq
+    compact = bool(int(os.environ.get("MI_BENCH_GRID2_COMPACT", "0")))
+    g2 = mi.Grid2.uniform(ctx, 0.0, 1.0 / (n3 - 1), n3, 0.0, 1.0 / (n3 - 1), n3, synth.config3_table(n3, dev), compact=compact)
+    q2 = synth.splitmix_uniform(0x5EED0004 + 0x1000 * rank, 2 * nq, dev)
+    zq = torch.empty(nq, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    wall, ev = timed_loop(ctx, lambda: g2.interp(q2[:nq], q2[nq:], out=zq), args.steps, args.warmup, barrier)
+    t = torch.tensor([wall, ev], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max = float(t[0])
+    alg = 24.0 * nq + 8.0 * n3 * n3                       # SURVEY 8(d): 16 B of queries + 8 B result, table once
+    ks = ev / args.steps
+    if rank == 0:
+        print(json.dumps({
+            "metric": "interpolated points/sec (fp64)", "value": world * nq * args.steps / wall_max, "unit": "points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "2D bilinear interp, 4096x4096 grid, %.0e scattered query points (BASELINE configs[2])" % nq,
+                       "queries_per_gpu": nq, "table_layout": "column pairs (2x input bytes)" if compact else "quad cells (4x input bytes)",
+                       "entry_point": "mi_interp2_f64_dev"},
+            "roofline": {"bound": "hbm", "achieved": alg / ks / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": alg / ks / 1e9 / HBM_PEAK_GBPS, "traffic": None, "kernel": "interp2_kernel", "kernel_ms": ks * 1e3,
+                         "algorithmic_bytes_per_launch": alg},
+            "cpu_baseline": None, "device": info["name"]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -156,12 +208,28 @@ def main():
     X, Y = synth.config_grid(args.ng)
     if args.table == "general":
         grid = mi.Grid1.from_nodes(ctx, X, Y, sanitise=False)
+    elif args.table == "nonuniform":
+        un = synth.splitmix_uniform(0x5EED0002, args.ng, torch.device("cpu")).numpy()
+        X = (np.arange(args.ng) + 0.5 * un) / args.ng
+        grid = mi.Grid1.from_nodes(ctx, X, Y, sanitise=False)
     else:
         grid = mi.Grid1.uniform(ctx, 0.0, 1.0 / (args.ng - 1), Y)
     ginfo = grid.info()
     nq = args.nq
-    # each rank's shard of the N*nq-query batch: SplitMix64 stream offset by rank
-    xq = synth.splitmix_uniform(SEED_Q + 0x1000 * rank, nq, dev)
+    if args.config == 3:
+        return bench_config3(args, ctx, info, dev, world, rank, barrier, dist)
+    strong = args.scaling == "strong" or args.shard_of > 0
+    if strong:
+        # ONE query set of args.nq elements (the headline's SplitMix64 stream), contiguous shard per rank
+        from armadillocudalinearinterpolation_amd import sharding
+        parts = args.shard_of if args.shard_of > 0 else world
+        lo, hi = sharding.shard_bounds(args.nq, 0 if args.shard_of > 0 else rank, parts)
+        lo -= lo & 1                                                      # 16-B aligned shard starts (vector kernels)
+        nq = hi - lo
+        xq = synth.splitmix_uniform(SEED_Q, nq, dev, offset=lo)
+    else:
+        # each rank's shard of the N*nq-query batch: SplitMix64 stream offset by rank
+        xq = synth.splitmix_uniform(SEED_Q + 0x1000 * rank, nq, dev)
     if args.queries == "sorted":
         xq = torch.sort(xq).values
     elif args.queries == "uniform":
@@ -179,16 +247,17 @@ def main():
     alg_bytes = 16.0 * nq + float(ginfo["table_bytes"])                              # per launch, per GPU
     kernel_s = ev / args.steps                                                        # this rank's avg launch
     achieved = alg_bytes / kernel_s / 1e9
+    traffic, traffic_note = measured_traffic(ginfo["mode"], args.queries, nq)
     result = {
         "metric": "interpolated points/sec (fp64)",
-        "value": world * nq * args.steps / wall_max,
+        "value": (args.nq if (strong and not args.shard_of) else world * nq) * args.steps / wall_max,
         "unit": "points/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": wall_max / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -198,12 +267,14 @@ def main():
             "queries_per_gpu": nq, "grid_nodes": args.ng, "table": args.table,
             "table_mode": ginfo["mode"], "table_bytes": ginfo["table_bytes"],
             "entry_point": "mi_interp1_f64_dev", "sharding": "queries/%d, table replicated, no collective" % world,
+            "query_set": ("one set of %d queries, contiguous shards of NQ/%d" % (args.nq, args.shard_of or world)) if strong
+                         else "every rank its own set of %d queries" % nq,
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(ginfo["mode"], args.queries, nq),
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
             "kernel": ("interp1_sweep_kernel<%d,...> (region sweep)" if (args.queries == "random" and ginfo["table_bytes"] >= (5 << 20)
-                                                                       and nq // 16384 >= 4 * info["compute_units"])
+                                                                       and nq // 16384 >= SWEEP_MIN_TILES_PER_CU * info["compute_units"])
                        else "interp1_vec_kernel<%d,...> (streaming)") % ginfo["mode"],
             "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
             "note": "achieved = (16 B/query + table bytes) / HIP-event time per launch; traffic: see profiles/",
@@ -277,7 +348,30 @@ def main():
             "note": "opt-in mi_edm_params.dedup_identical: one realisation evolved, events replicated to all rows; "
                     "outputs bit-identical to the full evolution (tests/test_edm_gpu.py); only valid for sigma = 0"}
         edm.close()
-    if world > 1 and not args.no_extra and args.dist_backend == "nccl":
+    if strong and world > 1 and args.dist_backend == "nccl":
+        # "also report compute + all-gather": the result shards reassembled on every GPU by an RCCL
+        # all-gather over xGMI inside the timed loop (ragged shards are padded to the largest)
+        from armadillocudalinearinterpolation_amd import sharding as _sh
+        sizes = [b - a for a, b in (_sh.shard_bounds(args.nq, r, world) for r in range(world))]
+        kmax = max(sizes) + 1
+        pad = torch.zeros(kmax, dtype=torch.float64, device=dev)
+        full = torch.empty(world * kmax, dtype=torch.float64, device=dev)
+
+        def step_ag():
+            grid.interp(xq, out=pad[:nq])
+            dist.all_gather_into_tensor(full, pad)
+        wall_ag, _ = timed_loop(ctx, step_ag, args.steps, args.warmup, barrier)
+        tt = torch.tensor([wall_ag], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        extra_strong = {"compute_only_ms_per_step": wall_max / args.steps * 1e3,
+                        "compute_plus_allgather_ms_per_step": float(tt[0]) / args.steps * 1e3,
+                        "points_per_s_compute_only": args.nq * args.steps / wall_max,
+                        "points_per_s_compute_plus_allgather": args.nq * args.steps / float(tt[0]),
+                        "allgather": "RCCL all_gather_into_tensor of %d x %d B shards over xGMI, in the timed loop" % (world, 8 * kmax)}
+        del pad, full
+    else:
+        extra_strong = None
+    if world > 1 and not args.no_extra and args.dist_backend == "nccl" and not strong:
         full = torch.empty(world * nq, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(full, yq)
         torch.cuda.synchronize()
@@ -295,6 +389,8 @@ def main():
         else:
             result["cpu_baseline"] = None
         result["extra"] = extra
+        if extra_strong:
+            result["strong_scaling"] = extra_strong
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -6,6 +6,8 @@
 //   mi355::Interp1Table tab(X, Y); tab(XI, YI)   table resident in HBM across calls
 //   mi355::interp2(X, Y, Z, XI, YI, ZI)     scattered bilinear, Z = arma::mat(Y.n_elem, X.n_elem)
 //   mi355::restrict_to_horizon(...)         RestrictKernel (EventDrivenMap.cu:769-785) on host vectors
+//   mi355::DeviceGroup grp(8); mi355::GroupInterp1Table tab(grp, X, Y); tab(XI, YI)
+//                                           the same call with the queries sharded over the GPUs of the node
 //
 // Error convention: the reference aborts on any device error (CUDA_CALL ->
 // fprintf(stderr) + exit(-1), EventDrivenMap.cu:18-54) and on bad arguments
@@ -126,5 +128,47 @@ inline void restrict_to_horizon(const arma::fvec& t0, const std::vector<uint16_t
                                out.memptr(), n),
           dev.get(), "mi_restrict_f32_host");
 }
+
+// Several GPUs of one node behind the same call shapes (mi_group_*): contiguous query shards, the table
+// replicated, one call per interpolation.  devices = {0, 1, ..}; a repeated ordinal rehearses the sharding on one GPU.
+class DeviceGroup {
+  public:
+    explicit DeviceGroup(int ndev) : g_(nullptr) { check(mi_group_create(ndev, nullptr, &g_), nullptr, "mi_group_create"); }
+    explicit DeviceGroup(const std::vector<int>& devices) : g_(nullptr)
+    {
+        check(mi_group_create((int)devices.size(), devices.data(), &g_), nullptr, "mi_group_create");
+    }
+    ~DeviceGroup() { mi_group_destroy(g_); }
+    DeviceGroup(const DeviceGroup&) = delete;
+    DeviceGroup& operator=(const DeviceGroup&) = delete;
+    mi_group* get() const { return g_; }
+    int size() const { return mi_group_size(g_); }
+
+  private:
+    mi_group* g_;
+};
+
+class GroupInterp1Table {
+  public:
+    GroupInterp1Table(DeviceGroup& grp, const arma::vec& X, const arma::vec& Y, bool sanitise = true) : grp_(grp), t_(nullptr)
+    {
+        if (X.n_elem != Y.n_elem) throw std::invalid_argument("interp1(): X and Y must have the same number of elements");
+        check(mi_group_grid1_create(grp_.get(), X.memptr(), Y.memptr(), X.n_elem, sanitise ? MI_GRID_SANITISE : 0u, &t_), nullptr,
+              "mi_group_grid1_create");
+    }
+    ~GroupInterp1Table() { mi_group_grid1_destroy(t_); }
+    GroupInterp1Table(const GroupInterp1Table&) = delete;
+    GroupInterp1Table& operator=(const GroupInterp1Table&) = delete;
+    void operator()(const arma::vec& XI, arma::vec& YI, double extrap_val = std::numeric_limits<double>::quiet_NaN()) const
+    {
+        YI.set_size(XI.n_elem);
+        check(mi_group_interp1_f64_host(grp_.get(), t_, XI.memptr(), YI.memptr(), XI.n_elem, extrap_val), nullptr,
+              "mi_group_interp1_f64_host");
+    }
+
+  private:
+    DeviceGroup& grp_;
+    mi_group_grid1* t_;
+};
 
 }  // namespace mi355

@@ -69,8 +69,19 @@ class Col {
     T& operator[](uword i) { return d_[i]; }
     const T& operator[](uword i) const { return d_[i]; }
     bool is_empty() const { return d_.empty(); }
+    // element-wise arithmetic (eagerly evaluated): what NewtonSolver.cpp:101,104,134,194 of the reference uses
+    Col operator-() const { Col r(*this); for (auto& x : r.d_) x = -x; return r; }
+    Col& operator+=(const Col& o) { same(o); for (uword i = 0; i < n_elem; ++i) d_[i] += o.d_[i]; return *this; }
+    Col& operator-=(const Col& o) { same(o); for (uword i = 0; i < n_elem; ++i) d_[i] -= o.d_[i]; return *this; }
+    Col& operator*=(T k) { for (auto& x : d_) x *= k; return *this; }
+    friend Col operator+(Col a, const Col& b) { a += b; return a; }
+    friend Col operator-(Col a, const Col& b) { a -= b; return a; }
+    friend Col operator*(Col a, T k) { a *= k; return a; }
+    friend Col operator*(T k, Col a) { a *= k; return a; }
+    Col head(uword n) const { if (n > n_elem) throw std::out_of_range("arma shim head()"); Col r(n); std::copy(d_.begin(), d_.begin() + n, r.d_.begin()); return r; }
 
   private:
+    void same(const Col& o) const { if (o.n_elem != n_elem) throw std::invalid_argument("arma shim: element-wise operation on vectors of different length"); }
     void sync() { n_elem = n_rows = d_.size(); }
     std::vector<T> d_;
 };
@@ -92,6 +103,19 @@ class Mat {   // column-major, like arma::Mat
     const T* colptr(uword j) const { return d_.data() + j * n_rows; }
     T& operator()(uword i, uword j) { return d_.at(i + j * n_rows); }
     const T& operator()(uword i, uword j) const { return d_.at(i + j * n_rows); }
+    // J.col(i) = v   (NewtonSolver.cpp:194)
+    struct ColRef {
+        Mat& m;
+        uword j;
+        ColRef& operator=(const Col<T>& v)
+        {
+            if (v.n_elem != m.n_rows) throw std::invalid_argument("arma shim col(): length mismatch");
+            std::copy(v.begin(), v.end(), m.colptr(j));
+            return *this;
+        }
+    };
+    ColRef col(uword j) { if (j >= n_cols) throw std::out_of_range("arma shim col()"); return ColRef{*this, j}; }
+    Col<T> col(uword j) const { if (j >= n_cols) throw std::out_of_range("arma shim col()"); Col<T> r(n_rows); std::copy(colptr(j), colptr(j) + n_rows, r.begin()); return r; }
 
   private:
     std::vector<T> d_;

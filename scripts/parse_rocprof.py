@@ -45,7 +45,7 @@ def main():
     if st:
         summary["kernel_stats_csv"] = open(st).read()
     pm = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_tcc"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_tcc", "pmc_tcc2"):
         f = find(os.path.join(out_dir, sub), "*counter_collection.csv")
         if not f:
             continue
@@ -57,7 +57,7 @@ def main():
     # HBM traffic of the interp1 kernel per launch, MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are
     # in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads -> x2.
     # the dominant interp1 kernel of the run (region-sweep or streaming), by average duration
-    dom = [k for k in summary["kernels"] if "interp1_sweep_kernel" in k or "interp1_vec_kernel" in k]
+    dom = [k for k in summary["kernels"] if "interp1_sweep_kernel" in k or "interp1_vec_kernel" in k or "interp2_kernel" in k or "interp1_sweep_pipe_kernel" in k]
     dom = max(dom, key=lambda k: summary["kernels"][k]["avg_us"]) if dom else None
     queries = sys.argv[3] if len(sys.argv) > 3 else "random"
     nq = int(sys.argv[4]) if len(sys.argv) > 4 else 100000000
@@ -68,7 +68,17 @@ def main():
             # 128-B requests (tallied at 64 B: half of it is missing from FETCH_SIZE); what is left of FETCH_SIZE
             # is table-gather misses, 64-B requests tallied in full (TCC_EA0_RDREQ and TCC_MISS agree, see README)
             stream = nq * 8.0
+            # size classes of the fabric reads, when collected: every request at its real size (round 2: all 14.1 M
+            # requests of the sweep kernel are 128-B requests, also the table-gather misses -- the "calibrated" figure
+            # of round 1 took those for 64 B and was 0.5 GB short)
+            sized = None
+            if "TCC_EA0_RDREQ_128B_sum" in cs and "TCC_EA0_RDREQ_sum" in cs:
+                n128 = cs["TCC_EA0_RDREQ_128B_sum"]["per_dispatch_median"]
+                n64 = cs.get("TCC_EA0_RDREQ_64B_sum", {"per_dispatch_median": 0.0})["per_dispatch_median"]
+                n32 = cs.get("TCC_EA0_RDREQ_32B_sum", {"per_dispatch_median": 0.0})["per_dispatch_median"]
+                sized = 128.0 * n128 + 64.0 * n64 + 32.0 * n32 + w * 1024.0
             summary.setdefault("traffic", {})[k] = {
+                "hbm_bytes_per_launch_by_request_size": sized,
                 "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                 "hbm_bytes_per_launch_raw": (f + w) * 1024.0,
                 "hbm_bytes_per_launch_doubled": (2.0 * f + w) * 1024.0,
@@ -84,16 +94,27 @@ def main():
         m = re.search(r"interp1_(?:vec|sweep)_kernel<(\d+)", k)
         if m:
             latest["interp1_mode%s_%s" % (m.group(1), queries)] = {
-                "nq": nq, "hbm_bytes_per_launch": t["hbm_bytes_per_launch_calibrated"],
+                "nq": nq,
+                "hbm_bytes_per_launch": t["hbm_bytes_per_launch_by_request_size"] or t["hbm_bytes_per_launch_doubled"],
+                "hbm_bytes_per_launch_calibrated_r01": t["hbm_bytes_per_launch_calibrated"],
                 "hbm_bytes_per_launch_doubled": t["hbm_bytes_per_launch_doubled"],
                 "hbm_bytes_per_launch_raw": t["hbm_bytes_per_launch_raw"],
                 "table_gather_bytes_beyond_l2": t["table_gather_bytes_beyond_l2"], "kernel": k,
                 "profile": "summary_%s.json" % tag,
-                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md section "
-                          "HBM: gfx950 FETCH_SIZE tallies a 128-B request as 64 B); calibrated on this kernel's known query "
-                          "stream: FETCH_SIZE*1024 + nq*4 + WRITE_SIZE*1024; 'doubled' = (2*FETCH_SIZE + WRITE_SIZE)*1024 is "
-                          "the upper bound; Infinity-Cache hits are counted"}
+                "method": "rocprofv3 --pmc passes, one counter group each (MI355X_MICROARCH.md section HBM: gfx950 FETCH_SIZE "
+                          "tallies every fabric read at 64 B): reads = 128*TCC_EA0_RDREQ_128B + 64*_64B + 32*_32B, writes = "
+                          "WRITE_SIZE*1024; without the size classes the 'doubled' figure (2*FETCH_SIZE + WRITE_SIZE)*1024; "
+                          "Infinity-Cache hits are counted"}
     if latest:
+        # stamp: the sources the profiled library was built from (bench.py quotes the figure only for the same build)
+        try:
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from armadillocudalinearinterpolation_amd import _build
+            stamp = _build.source_hash()
+        except Exception:
+            stamp = None
+        for e in latest.values():
+            e["source_sha256"] = stamp
         json.dump(latest, open(os.path.join(out_dir, "traffic_latest.json"), "w"), indent=1)
     dst = os.path.join(out_dir, "summary_%s.json" % tag)
     json.dump(summary, open(dst, "w"), indent=1)

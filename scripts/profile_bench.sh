@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats + separate PMC passes for bench.py.
-# Usage: scripts/profile_bench.sh <round-tag> [random|sorted|uniform]      outputs under gpurun_out/prof_<tag>/
+# Usage: scripts/profile_bench.sh <round-tag> [random|sorted|uniform] [extra bench.py args, e.g. --config 3 | --table nonuniform]
+# outputs under gpurun_out/prof_<tag>/
 # The python program itself follows `--` (no env/bash hop: the profiler preloads into the process).
 set -u
 TAG=${1:-r01}
@@ -10,7 +11,8 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$REPO"
-ARGS="bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --queries $QUERIES"
+shift; shift
+ARGS="bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --queries $QUERIES $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ARGS > "$OUT/stats.log" 2>&1
 echo "stats rc=$?"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 $ARGS > "$OUT/pmc_fetch.log" 2>&1
@@ -19,4 +21,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write
 echo "pmc write rc=$?"
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d "$OUT/pmc_tcc" -- python3 $ARGS > "$OUT/pmc_tcc.log" 2>&1
 echo "pmc tcc rc=$?"
+# size classes of the L2's fabric reads: the bytes that really left L2 (FETCH_SIZE tallies every request at 64 B)
+rocprofv3 --pmc TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d "$OUT/pmc_tcc2" -- python3 $ARGS > "$OUT/pmc_tcc2.log" 2>&1
+echo "pmc tcc2 rc=$?"
 python3 scripts/parse_rocprof.py "$OUT" "$TAG" "$QUERIES"

@@ -77,3 +77,20 @@ def test_public_header_is_plain_c99(tmp_path):
            "-o", str(exe), "-L", lib_dir, "-lmi355interp", "-Wl,-rpath," + lib_dir]
     out = subprocess.run(cmd, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+
+
+def test_shard_bounds_host_arithmetic():
+    """mi_shard_bounds is host-only (no GPU needed): contiguous, balanced, covering; equals sharding.shard_bounds."""
+    from armadillocudalinearinterpolation_amd import sharding
+    L = _lib.load()
+    lo, hi = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    for n in (0, 1, 7, 8, 100, 10**8 + 3, 2**33 + 5):
+        for world in (1, 2, 3, 8, 64):
+            b = []
+            for r in range(world):
+                L.mi_shard_bounds(n, r, world, ctypes.byref(lo), ctypes.byref(hi))
+                b.append((lo.value, hi.value))
+            assert b == [sharding.shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [h - l for l, h in b]
+            assert max(sizes) - min(sizes) <= 1

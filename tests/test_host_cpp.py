@@ -83,6 +83,8 @@ def test_arma_wrappers_match_oracle(tmp_path):
     assert np.array_equal(rd("w_interp1.bin"), ref, equal_nan=True)
     assert np.array_equal(rd("w_table_nan.bin"), ref, equal_nan=True)
     assert np.array_equal(rd("w_table_extrap.bin"), oracle.interp1_arma(X, Y, XI, extrap=-1.0))
+    assert np.array_equal(rd("w_group_table.bin"), ref, equal_nan=True)            # query shards over a device group
+    assert np.array_equal(rd("w_group1_table_extrap.bin"), oracle.interp1_arma(X, Y, XI, extrap=-1.0))
     xr = np.fromfile(os.path.join(tmp_path, "w_restrict.bin"), dtype=np.float32)
     assert np.array_equal(xr, oracle.restrict_f32([4, 4.5, 1, 4.99], [512, 100, 1023, 0], [6, 5.25, 9, 5.01],
                                                   [514, 101, 1023, 1], 5.0, 3.0, 1024))
