@@ -352,15 +352,17 @@ def test_scattered_bilinear_seeded(mi_ctx):
 
 # ---------------------------------------------------------------- BASELINE-size property tests
 def test_config2_full_size_properties(mi_ctx):
-    """1e8 random queries over a 1e6-node table (BASELINE.json configs[1]): properties + sampled parity."""
+    """1e8 random queries over a 1e6-node table (BASELINE.json configs[1]), the very query set bench.py times
+    (SplitMix64 seed 0x5EED0003, generated on the device): properties + sampled parity."""
     import armadillocudalinearinterpolation_amd as mi
+    from armadillocudalinearinterpolation_amd import synth
     import torch
     NG, NQ = 10**6, 10**8
     X = np.arange(NG) / (NG - 1)
     Y = np.sin(2 * np.pi * X) + 0.5 * X
     grid = mi.Grid1.from_nodes(mi_ctx, X, Y, sanitise=False)
-    g = torch.Generator(device="cuda:0").manual_seed(0x5EED0003)
-    xq = torch.rand(NQ, dtype=torch.float64, device="cuda:0", generator=g)
+    xq = synth.splitmix_uniform(0x5EED0003, NQ, torch.device("cuda", 0))
+    assert np.array_equal(xq[:1000].cpu().numpy(), oracle.splitmix_uniform(0x5EED0003, 1000))   # the oracle's stream
     out = grid.interp(xq)
     # sampled bit parity with the oracle (2e5 queries spread over the vector)
     idx = torch.arange(0, NQ, NQ // 200000, device="cuda:0")
@@ -475,19 +477,24 @@ def test_region_sweep_path_equals_streaming_path(mi_ctx, kind):
 
 
 def test_config3_full_grid_sampled(mi_ctx):
-    """4096x4096 table (BASELINE.json configs[2]), 2e7 scattered queries: sampled parity + bilinear exactness."""
+    """4096x4096 table (BASELINE.json configs[2]) at its full size: the 1e8 scattered queries bench.py times (SplitMix64
+    seed 0x5EED0004: first half x, second half y), sampled parity (2e5 queries spread over the vector) + bilinear
+    exactness at every one of the 1e8 points + both resident layouts bit-equal."""
     import armadillocudalinearinterpolation_amd as mi
+    from armadillocudalinearinterpolation_amd import synth
     import torch
     n = 4096
     ax = np.arange(n) / (n - 1)
     Z = np.sin(2 * np.pi * ax)[:, None] * np.cos(2 * np.pi * ax)[None, :] + ax[None, :] * ax[:, None]
     grid = mi.Grid2.uniform(mi_ctx, 0.0, 1.0 / (n - 1), n, 0.0, 1.0 / (n - 1), n, Z)
-    g = torch.Generator(device="cuda:0").manual_seed(0x5EED0004)
-    NQ = 20_000_000
-    xq = torch.rand(NQ, dtype=torch.float64, device="cuda:0", generator=g)
-    yq = torch.rand(NQ, dtype=torch.float64, device="cuda:0", generator=g)
+    NQ = 100_000_000
+    q2 = synth.splitmix_uniform(0x5EED0004, 2 * NQ, torch.device("cuda", 0))
+    xq, yq = q2[:NQ], q2[NQ:]
     out = grid.interp(xq, yq)
-    idx = torch.arange(0, NQ, 100, device="cuda:0")
+    compact = mi.Grid2.uniform(mi_ctx, 0.0, 1.0 / (n - 1), n, 0.0, 1.0 / (n - 1), n, Z, compact=True)
+    assert torch.equal(compact.interp(xq, yq), out)
+    compact.close()
+    idx = torch.arange(0, NQ, 500, device="cuda:0")
     ref = oracle.interp2_bilinear_uniform(0.0, 1.0 / (n - 1), n, 0.0, 1.0 / (n - 1), n, Z,
                                           xq[idx].cpu().numpy(), yq[idx].cpu().numpy(), nthreads=8)
     assert np.array_equal(out[idx].cpu().numpy(), ref)
