@@ -83,7 +83,7 @@ def main():
                 "hbm_bytes_per_launch_raw": (f + w) * 1024.0,
                 "hbm_bytes_per_launch_doubled": (2.0 * f + w) * 1024.0,
                 "hbm_bytes_per_launch_calibrated": f * 1024.0 + 0.5 * stream + w * 1024.0,
-                "table_gather_bytes_beyond_l2": max(0.0, f * 1024.0 - 0.5 * stream),
+                "table_gather_bytes_beyond_l2": (sized - w * 1024.0 - stream) if sized else max(0.0, f * 1024.0 - 0.5 * stream),
                 "note": "doubled = (2*FETCH_SIZE + WRITE_SIZE)*1024 (every read taken as a 128-B request tallied at "
                         "64 B); calibrated = FETCH_SIZE*1024 + nq*4 + WRITE_SIZE*1024 (only the 16 B/lane query "
                         "stream is wide; table-gather misses are 64-B requests counted in full)"}
