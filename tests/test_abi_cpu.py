@@ -69,14 +69,26 @@ def test_public_header_is_plain_c99(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "c_abi.c"
     src.write_text('#include "mi355_interp.h"\n'
-                   "int main(void) { mi_edm_params p; mi_edm_default_params(&p);\n"
-                   "  return (p.n_spikes == 3u && mi_abi_version() == MI355_INTERP_ABI_VERSION) ? 0 : 1; }\n")
+                   "/* every multi-GPU entry point is referenced, so the link fails if one is missing or mis-declared */\n"
+                   "typedef void (*fn)(void);\n"
+                   "static fn group_api[] = { (fn)mi_group_create, (fn)mi_group_destroy, (fn)mi_group_size,\n"
+                   "  (fn)mi_group_ctx, (fn)mi_group_synchronize, (fn)mi_group_set_reduce, (fn)mi_group_grid1_create,\n"
+                   "  (fn)mi_group_grid1_destroy, (fn)mi_group_interp1_f64_host, (fn)mi_group_interp1_f64_dev,\n"
+                   "  (fn)mi_group_edm_create, (fn)mi_group_edm_destroy, (fn)mi_group_edm_set_params,\n"
+                   "  (fn)mi_group_edm_compute_f, (fn)mi_group_edm_shard, (fn)mi_group_edm_shard_bounds };\n"
+                   "int main(void) { mi_edm_params p; size_t lo, hi; double z[3] = {0.3, 0.7, 1.4}, f[3], sc[MI_EDM_PARTIAL_LEN(3)] = {3, 3, 3, 2, 9, 9, 9};\n"
+                   "  mi_edm_default_params(&p); mi_shard_bounds(10, 1, 3, &lo, &hi);      /* host-only calls really run */\n"
+                   "  if (mi_edm_residual_from_sums(&p, z, sc, f) != MI_OK) return 2;\n"
+                   "  return (p.n_spikes == 3u && p.mean_quirk == 1 && lo == 4 && hi == 7 && group_api[0] &&\n"
+                   "          mi_abi_version() == MI355_INTERP_ABI_VERSION) ? 0 : 1; }\n")
     exe = tmp_path / "c_abi"
     lib_dir = os.path.join(root, "armadillocudalinearinterpolation_amd")
     cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
            "-o", str(exe), "-L", lib_dir, "-lmi355interp", "-Wl,-rpath," + lib_dir]
     out = subprocess.run(cmd, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
 
 
 def test_shard_bounds_host_arithmetic():
