@@ -67,7 +67,8 @@ bool pin_host(const void* p, size_t bytes)
         if (it->second.bytes >= bytes) { ++it->second.refs; return true; }
         return false;   // a longer range from the same base while a shorter one is pinned: blocking copies for this call
     }
-    const hipError_t e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault);
+    // portable: a group call (mi_group_interp1_f64_host) copies from / to the same range on several devices
+    const hipError_t e = hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterPortable);
     if (e != hipSuccess) { (void)hipGetLastError(); return false; }   // pinned by the caller already, or not pinnable
     t.emplace(p, PinEntry{bytes, 1u});
     return true;

@@ -56,6 +56,9 @@ def parse():
                          "all-gather both reported")
     ap.add_argument("--shard-of", type=int, default=0, metavar="P",
                     help="1-GPU rehearsal of the strong-scaling shard sizes: time this GPU on shard 0 of P (NQ/P queries)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N > 1 code path (process group, barriers, all-reduce of the timings, all-gather) with a "
+                         "world of ONE rank: rehearsal of the RCCL calls on a one-GPU box")
     ap.add_argument("--config", type=int, choices=[2, 3], default=2,
                     help="2 (default): BASELINE configs[1], the 1-D headline; 3: configs[2], 4096^2 bilinear, 1e8 scattered "
                          "queries as the timed workload (for profiling interp2_kernel; same JSON contract)")
@@ -129,7 +132,7 @@ def measured_traffic(mode, queries, nq):
     return None, "no committed PMC profile covers this configuration"
 
 
-def bench_config3(args, ctx, info, dev, world, rank, barrier, dist):
+def bench_config3(args, ctx, info, dev, world, rank, barrier, dist, dist_on):
     """BASELINE configs[2] as the timed workload: 4096 x 4096 fp64 table (arma::mat layout), 1e8 scattered (x, y) queries per
     rank (SplitMix64 seed 0x5EED0004), one step = one mi_interp2_f64_dev pass.  Same JSON contract as the headline."""
     import torch
@@ -139,21 +142,31 @@ def bench_config3(args, ctx, info, dev, world, rank, barrier, dist):
     n3, nq = 4096, args.nq
     compact = bool(int(os.environ.get("MI_BENCH_GRID2_COMPACT", "0")))
     g2 = mi.Grid2.uniform(ctx, 0.0, 1.0 / (n3 - 1), n3, 0.0, 1.0 / (n3 - 1), n3, synth.config3_table(n3, dev), compact=compact)
-    q2 = synth.splitmix_uniform(0x5EED0004 + 0x1000 * rank, 2 * nq, dev)
+    strong = args.scaling == "strong" or args.shard_of > 0
+    if strong:      # ONE set of args.nq query pairs (x = stream[0:NQ], y = stream[NQ:2NQ]), contiguous shard per rank
+        from armadillocudalinearinterpolation_amd import sharding
+        lo, hi = sharding.shard_bounds(args.nq, 0 if args.shard_of > 0 else rank, args.shard_of or world)
+        lo -= lo & 1
+        nq = hi - lo
+        q2 = torch.cat([synth.splitmix_uniform(0x5EED0004, nq, dev, offset=lo),
+                        synth.splitmix_uniform(0x5EED0004, nq, dev, offset=args.nq + lo)])
+    else:
+        q2 = synth.splitmix_uniform(0x5EED0004 + 0x1000 * rank, 2 * nq, dev)
     zq = torch.empty(nq, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
     wall, ev = timed_loop(ctx, lambda: g2.interp(q2[:nq], q2[nq:], out=zq), args.steps, args.warmup, barrier)
     t = torch.tensor([wall, ev], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t[0])
     alg = 24.0 * nq + 8.0 * n3 * n3                       # 16 B of queries + 8 B result, table once
     ks = ev / args.steps
     if rank == 0:
         print(json.dumps({
-            "metric": "interpolated points/sec (fp64)", "value": world * nq * args.steps / wall_max, "unit": "points/s",
+            "metric": "interpolated points/sec (fp64)",
+            "value": (args.nq if (strong and not args.shard_of) else world * nq) * args.steps / wall_max, "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D bilinear interp, 4096x4096 grid, %.0e scattered query points (BASELINE configs[2])" % nq,
                        "queries_per_gpu": nq, "table_layout": "column pairs (2x input bytes)" if compact else "quad cells (4x input bytes)",
                        "entry_point": "mi_interp2_f64_dev"},
@@ -161,7 +174,7 @@ def bench_config3(args, ctx, info, dev, world, rank, barrier, dist):
                          "frac": alg / ks / 1e9 / HBM_PEAK_GBPS, "traffic": None, "kernel": "interp2_kernel", "kernel_ms": ks * 1e3,
                          "algorithmic_bytes_per_launch": alg},
             "cpu_baseline": None, "device": info["name"]}), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -175,8 +188,12 @@ def main():
     import armadillocudalinearinterpolation_amd as mi
     from armadillocudalinearinterpolation_amd import synth
 
+    if args.force_dist:
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29611")):
+            os.environ.setdefault(k, v)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    dist_on = world > 1 or args.force_dist
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         print("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus,
@@ -190,7 +207,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
@@ -217,7 +234,7 @@ def main():
     ginfo = grid.info()
     nq = args.nq
     if args.config == 3:
-        return bench_config3(args, ctx, info, dev, world, rank, barrier, dist)
+        return bench_config3(args, ctx, info, dev, world, rank, barrier, dist, dist_on)
     strong = args.scaling == "strong" or args.shard_of > 0
     if strong:
         # ONE query set of args.nq elements (the headline's SplitMix64 stream), contiguous shard per rank
@@ -239,7 +256,7 @@ def main():
 
     wall, ev = timed_loop(ctx, lambda: grid.interp(xq, out=yq), args.steps, args.warmup, barrier)
     t = torch.tensor([wall, ev], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max, ev_max = float(t[0]), float(t[1])
 
@@ -348,7 +365,7 @@ def main():
             "note": "opt-in mi_edm_params.dedup_identical: one realisation evolved, events replicated to all rows; "
                     "outputs bit-identical to the full evolution (tests/test_edm_gpu.py); only valid for sigma = 0"}
         edm.close()
-    if strong and world > 1 and args.dist_backend == "nccl":
+    if strong and dist_on and args.dist_backend == "nccl":
         # "also report compute + all-gather": the result shards reassembled on every GPU by an RCCL
         # all-gather over xGMI inside the timed loop (ragged shards are padded to the largest)
         from armadillocudalinearinterpolation_amd import sharding as _sh
@@ -371,7 +388,7 @@ def main():
         del pad, full
     else:
         extra_strong = None
-    if world > 1 and not args.no_extra and args.dist_backend == "nccl" and not strong:
+    if dist_on and not args.no_extra and args.dist_backend == "nccl" and not strong:
         full = torch.empty(world * nq, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(full, yq)
         torch.cuda.synchronize()
@@ -392,7 +409,7 @@ def main():
         if extra_strong:
             result["strong_scaling"] = extra_strong
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
