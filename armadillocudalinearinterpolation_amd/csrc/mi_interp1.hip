@@ -639,8 +639,12 @@ constexpr int kPipeGroup = 512;                          // lanes per group = kS
 constexpr int kPipeThreads = 2 * kPipeGroup;
 static_assert(kSweepTile == kPipeGroup * kSweepK, "one group covers a tile with kSweepK queries per lane");
 
-// test hook (mi_debug_sweep_timing): when set, lane 0 of each group accumulates wall_clock64 ticks (100 MHz) per role and
+// test hook (mi_debug_sweep_timing; compiled in with -DMI_PIPE_TIMING=1 only: the accumulators cost the pipelined kernel
+// registers it does not have): when set, lane 0 of each group accumulates wall_clock64 ticks (100 MHz) per role and
 // schedule interval into [workgroup][group][role: 0 gather, 1 prepare][interval 0..5]
+#ifndef MI_PIPE_TIMING
+#define MI_PIPE_TIMING 0
+#endif
 __device__ unsigned long long* g_pipe_timing = nullptr;
 
 __device__ __forceinline__ void pipe_barrier()
@@ -703,11 +707,12 @@ __global__ __launch_bounds__(kPipeThreads) void interp1_sweep_pipe_kernel(G1Dev 
             }
         }
     };
-    auto load_tile = [&](long it) { load_part(it, 0, kSweepK / 2); };
+    [[maybe_unused]] auto load_tile = [&](long it) { load_part(it, 0, kSweepK / 2); };
     for (int b = threadIdx.x; b < 2 * kSweepBins; b += kPipeThreads) (&hist[0][0])[b] = 0;
     if (SCHED == 0 && grp == 0 && nloc > 0) load_tile(0);
     pipe_barrier();
     unsigned* const myhist = hist[grp];
+#if MI_PIPE_TIMING
     unsigned long long* const tdbg = g_pipe_timing;
     unsigned long long tacc[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
     unsigned long long tlast = tdbg ? wall_clock64() : 0;
@@ -717,6 +722,9 @@ __global__ __launch_bounds__(kPipeThreads) void interp1_sweep_pipe_kernel(G1Dev 
         tacc[role][slot] += now_ - tlast;                               \
         tlast = now_;                                                   \
     }
+#else
+#define MI_PIPE_STAMP(role, slot)
+#endif
     // barrier among the 8 waves of this group only: a monotonic arrival counter in LDS
     unsigned gb_target = 0;
     auto group_barrier = [&]() {
@@ -770,6 +778,8 @@ __global__ __launch_bounds__(kPipeThreads) void interp1_sweep_pipe_kernel(G1Dev 
                 __builtin_nontemporal_store(v, o2 + tid + u * kPipeGroup);
             }
         }
+        // (also measured: leaving the last quarter / eighth of the loads to the start of the prepare step -- 0.682 / 0.671 ms
+        // against 0.672 ms: the burst's cost moves with it)
         if (SCHED == 0 && it + 2 < nloc) {   // (it = -1: group 1's first tile)
             load_tile(it + 2);
         } else {
@@ -874,10 +884,12 @@ __global__ __launch_bounds__(kPipeThreads) void interp1_sweep_pipe_kernel(G1Dev 
         }
     }
 #undef MI_PIPE_STAMP
+#if MI_PIPE_TIMING
     if (tdbg && tid == 0) {
         for (int r = 0; r < 2; ++r)
             for (int k = 0; k < 6; ++k) tdbg[((size_t)blockIdx.x * 2 + grp) * 12 + r * 6 + k] = tacc[r][k];
     }
+#endif
     if (tail && last_wg && grp == 0) {       // ragged tail (< one tile), four queries per lane at a time
         const double* tq = xq + ntiles * kSweepTile;
         double* to = yq + ntiles * kSweepTile;
@@ -945,15 +957,15 @@ mi_status launch_vec(mi_ctx* ctx, const G1Dev& d, const double* xq, double* yq, 
     return launch_vec_shape<MODE, FORMULA, kBlock, MI_INTERP1_VPL>(ctx, d, xq, yq, nq, extrap, nullptr, probe);
 }
 
-// MI_SWEEP_VARIANT = 1 (default): one 512-lane workgroup per CU, the phases of a tile one after the other;
-// 2: the pipelined form (two wave groups per CU swapping roles; 0.67-0.73 ms against 0.71 ms, see DESIGN.md section 4:
-// not consistently faster, kept as an A-B hook).  Read once.
+// MI_SWEEP_VARIANT = 2 (default): the pipelined form (two wave groups per CU swapping roles: 0.657-0.672 ms per 1e8
+// queries, 7 % less than form 1 on the same box in every run, profiles/r02_sweep_pipelined_phases.log);
+// 1: one 512-lane workgroup per CU, the phases of a tile one after the other (0.710-0.716 ms).  Read once.
 inline int sweep_variant()
 {
     static const int v = [] {
         const char* e = getenv("MI_SWEEP_VARIANT");
-        const int x = e ? atoi(e) : 1;
-        return (x == 1 || x == 2) ? x : 1;
+        const int x = e ? atoi(e) : 2;
+        return (x == 1 || x == 2) ? x : 2;
     }();
     return v;
 }
@@ -1040,7 +1052,10 @@ mi_status launch_mode(mi_ctx* ctx, const G1Dev& d, size_t table_bytes, const dou
         return MI_OK;
     }
     // one launch: sort-and-gather tiles, the ragged tail, and the probe for the next call (flags[0] is a constant 0)
-    if (sweep_variant() == 2) {
+    // the pipelined form pays one extra (fill) step per workgroup: it wins from about 16 tiles per CU (1e8 queries: 0.66-0.69
+    // against 0.71 ms) and is 1 % behind at 3-12 tiles per CU (profiles/r02_strong_scaling_shards.log)
+    static const bool force_pipe = getenv("MI_SWEEP_VARIANT") != nullptr;
+    if (sweep_variant() == 2 && (force_pipe || ntiles >= (size_t)cus * 16)) {
         const unsigned pgrid = (unsigned)std::min<size_t>(ntiles, (size_t)cus);   // one 1024-lane workgroup per CU
         static const int sched = [] { const char* e = getenv("MI_SWEEP_SCHED"); return e ? atoi(e) : 0; }();   // A-B hook
         if (sched == 1)

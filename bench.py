@@ -132,6 +132,17 @@ def measured_traffic(mode, queries, nq):
     return None, "no committed PMC profile covers this configuration"
 
 
+def kernel_label(args, ginfo, nq, info):
+    """which kernel launch_mode (csrc/mi_interp1.hip) picks for this call: region sweep for unordered queries over a table
+    beyond L2 with at least SWEEP_MIN_TILES_PER_CU tiles per CU (pipelined form from 16 tiles per CU), else streaming"""
+    tiles_per_cu = nq // 16384 / float(info["compute_units"])
+    if args.queries == "random" and ginfo["table_bytes"] >= (5 << 20) and tiles_per_cu >= SWEEP_MIN_TILES_PER_CU:
+        pipe = tiles_per_cu >= 16 and os.environ.get("MI_SWEEP_VARIANT", "2") == "2"
+        return ("interp1_sweep_pipe_kernel<%d,...> (region sweep, pipelined form)" if pipe
+                else "interp1_sweep_kernel<%d,...> (region sweep)") % ginfo["mode"]
+    return "interp1_vec_kernel<%d,...> (streaming)" % ginfo["mode"]
+
+
 def bench_config3(args, ctx, info, dev, world, rank, barrier, dist, dist_on):
     """BASELINE configs[2] as the timed workload: 4096 x 4096 fp64 table (arma::mat layout), 1e8 scattered (x, y) queries per
     rank (SplitMix64 seed 0x5EED0004), one step = one mi_interp2_f64_dev pass.  Same JSON contract as the headline."""
@@ -290,9 +301,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
-            "kernel": ("interp1_sweep_kernel<%d,...> (region sweep)" if (args.queries == "random" and ginfo["table_bytes"] >= (5 << 20)
-                                                                       and nq // 16384 >= SWEEP_MIN_TILES_PER_CU * info["compute_units"])
-                       else "interp1_vec_kernel<%d,...> (streaming)") % ginfo["mode"],
+            "kernel": kernel_label(args, ginfo, nq, info),
             "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
             "note": "achieved = (16 B/query + table bytes) / HIP-event time per launch; traffic: see profiles/",
         },

@@ -58,7 +58,7 @@ def main():
     # in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads -> x2.
     # the dominant interp1 kernel of the run (region-sweep or streaming), by average duration
     dom = [k for k in summary["kernels"] if "interp1_sweep_kernel" in k or "interp1_vec_kernel" in k or "interp2_kernel" in k or "interp1_sweep_pipe_kernel" in k]
-    dom = max(dom, key=lambda k: summary["kernels"][k]["avg_us"]) if dom else None
+    dom = max(dom, key=lambda k: summary["kernels"][k]["avg_us"] * summary["kernels"][k]["calls"]) if dom else None   # by total time
     queries = sys.argv[3] if len(sys.argv) > 3 else "random"
     nq = int(sys.argv[4]) if len(sys.argv) > 4 else 100000000
     for k, cs in pm.items():
@@ -91,7 +91,7 @@ def main():
     import re
     latest = {}
     for k, t in summary.get("traffic", {}).items():
-        m = re.search(r"interp1_(?:vec|sweep)_kernel<(\d+)", k)
+        m = re.search(r"interp1_(?:vec|sweep_pipe|sweep)_kernel<(\d+)", k)
         if m:
             latest["interp1_mode%s_%s" % (m.group(1), queries)] = {
                 "nq": nq,

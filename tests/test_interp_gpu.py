@@ -555,3 +555,42 @@ def test_host_path_error_leaves_nothing_pinned(mi_ctx, monkeypatch):
     assert L.mi_debug_pinned_ranges() == 0
     idx = np.arange(0, nq, 4099)
     assert np.array_equal(got[idx], oracle.interp1_bracket(X, Y, xi[idx]))
+
+
+def test_both_sweep_kernel_forms_are_bit_identical(tmp_path):
+    """The region sweep has two forms (MI_SWEEP_VARIANT, read once per process): the pipelined two-group kernel (default)
+    and the one-phase-after-the-other kernel.  Each runs in a process of its own on the same seeded inputs (closed-form
+    and {x,y} tables, ragged tail) and must reproduce the streaming kernel -- hence each other -- bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = r"""
+import sys, numpy as np, torch, hashlib
+sys.path.insert(0, %r)
+import armadillocudalinearinterpolation_amd as mi
+from armadillocudalinearinterpolation_amd import synth
+ctx = mi.Context(0)
+out = []
+for kind in ("closed", "jitter"):
+    ng = 1_000_000
+    X = np.arange(ng) / (ng - 1)
+    if kind == "jitter":
+        X = (np.arange(ng) + 0.5 * synth.splitmix_uniform(7, ng, torch.device("cpu")).numpy()) / ng
+    Y = np.sin(2 * np.pi * X) + 0.5 * X
+    grid = mi.Grid1.from_nodes(ctx, X, Y, sanitise=False)
+    xq = synth.splitmix_uniform(11, 20_000_000 + 12_345, torch.device("cuda", 0)) * 1.02 - 0.01
+    ctx.set_query_order(1)                      # unordered: region sweep
+    a = grid.interp(xq)
+    ctx.set_query_order(2)                      # ordered: streaming kernel
+    b = grid.interp(xq)
+    assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), kind
+    out.append(hashlib.sha256(a.cpu().numpy().tobytes()).hexdigest())
+print("DIGEST", " ".join(out))
+""" % root
+    digests = []
+    for variant in ("1", "2"):
+        env = dict(os.environ, MI_SWEEP_VARIANT=variant)
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1]
