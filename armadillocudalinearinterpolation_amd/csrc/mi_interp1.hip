@@ -708,6 +708,16 @@ __global__ __launch_bounds__(kPipeThreads) void interp1_sweep_pipe_kernel(G1Dev 
         }
     };
     [[maybe_unused]] auto load_tile = [&](long it) { load_part(it, 0, kSweepK / 2); };
+    auto store_tile = [&](long it) {
+        d2* o2 = reinterpret_cast<d2*>(yq + ((size_t)blockIdx.x + (size_t)it * gridDim.x) * kSweepTile);
+#pragma unroll
+        for (int u = 0; u < kSweepK / 2; ++u) {
+            d2 v;
+            v.x = q[2 * u];
+            v.y = q[2 * u + 1];
+            __builtin_nontemporal_store(v, o2 + tid + u * kPipeGroup);
+        }
+    };
     for (int b = threadIdx.x; b < 2 * kSweepBins; b += kPipeThreads) (&hist[0][0])[b] = 0;
     if (SCHED == 0 && grp == 0 && nloc > 0) load_tile(0);
     pipe_barrier();
@@ -768,18 +778,10 @@ __global__ __launch_bounds__(kPipeThreads) void interp1_sweep_pipe_kernel(G1Dev 
         }
         pipe_barrier();
         MI_PIPE_STAMP(0, 1)                   // ... the other group's tile goes in meanwhile
-        if (act) {                           // results to HBM; nothing waited for
-            d2* o2 = reinterpret_cast<d2*>(yq + ((size_t)blockIdx.x + (size_t)it * gridDim.x) * kSweepTile);
-#pragma unroll
-            for (int u = 0; u < kSweepK / 2; ++u) {
-                d2 v;
-                v.x = q[2 * u];
-                v.y = q[2 * u + 1];
-                __builtin_nontemporal_store(v, o2 + tid + u * kPipeGroup);
-            }
-        }
-        // (also measured: leaving the last quarter / eighth of the loads to the start of the prepare step -- 0.682 / 0.671 ms
-        // against 0.672 ms: the burst's cost moves with it)
+        if (act) store_tile(it);             // results to HBM; nothing waited for
+        // Stores and loads are issued HERE, while nobody gathers (the other group scatters into LDS): measured against
+        // leaving the last quarter / eighth of the loads (0.682 / 0.671 ms vs 0.672 ms) or all stores and loads (0.712 vs
+        // 0.665 ms) to the start of this group's prepare step, where they would run beside the other group's gather rounds
         if (SCHED == 0 && it + 2 < nloc) {   // (it = -1: group 1's first tile)
             load_tile(it + 2);
         } else {
