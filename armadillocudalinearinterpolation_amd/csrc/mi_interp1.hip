@@ -466,6 +466,47 @@ __global__ __launch_bounds__(kLdsBlock) void interp1_lds_kernel(G1Dev g, const d
 // 256x32x2/CU 0.872 ms, 1024x16 0.823, 512x32 0.787 (64 regions), 0.770 (256), 0.797 (1024); with the up/down
 // order 0.69 ms.  Phase times, the L2 request-rate ceiling (2.7e11 gathers/s chip-wide) and the overlap schemes
 // that did not pay: DESIGN.md section 4, profiles/r01_exp_region_sweep_phases.log, r01_exp_gather_rate.log.
+// Experiment hook (off unless MI_STREAM_LD / MI_STREAM_ST are given at build time, e.g. -DMI_STREAM_LD=2 -DMI_STREAM_ST=2;
+// simple form and SCHED 0 of the pipelined form only): the query/result streams of the sweep kernels with explicit
+// cache-policy bits -- 0 none, 1 nt, 2 sc1 nt, 3 sc0 sc1 nt, 4 sc0 sc1, 5 sc0 nt, 6 sc1 -- to see whether any policy keeps
+// the streams from displacing the table in L2.  Result: profiles/r02_exp_stream_cache_policy.log
+#if defined(MI_STREAM_LD) || defined(MI_STREAM_ST)
+#define MI_STREAM_ASM 1
+#ifndef MI_STREAM_LD
+#define MI_STREAM_LD 1
+#endif
+#ifndef MI_STREAM_ST
+#define MI_STREAM_ST 1
+#endif
+#define MI_POLICY_BITS_0 ""
+#define MI_POLICY_BITS_1 "nt"
+#define MI_POLICY_BITS_2 "sc1 nt"
+#define MI_POLICY_BITS_3 "sc0 sc1 nt"
+#define MI_POLICY_BITS_4 "sc0 sc1"
+#define MI_POLICY_BITS_5 "sc0 nt"
+#define MI_POLICY_BITS_6 "sc1"
+#define MI_POLICY_CAT(a, b) a##b
+#define MI_POLICY_BITS(n) MI_POLICY_CAT(MI_POLICY_BITS_, n)
+#define MI_STREAM_LD_BITS MI_POLICY_BITS(MI_STREAM_LD)
+#define MI_STREAM_ST_BITS MI_POLICY_BITS(MI_STREAM_ST)
+__device__ __forceinline__ d2 stream_load(const d2* p)      // the caller waits (s_waitcnt vmcnt(0)) before the first use
+{
+    d2 v;
+    asm volatile("global_load_dwordx4 %0, %1, off " MI_STREAM_LD_BITS : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void stream_store(d2 v, d2* p)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off " MI_STREAM_ST_BITS "\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void stream_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else
+#define MI_STREAM_ASM 0
+__device__ __forceinline__ d2 stream_load(const d2* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stream_store(d2 v, d2* p) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void stream_wait() {}
+#endif
+
 #ifndef MI_SWEEP_THREADS
 #define MI_SWEEP_THREADS 512
 #endif
@@ -507,10 +548,11 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
         double q[kSweepK];
 #pragma unroll
         for (int u = 0; u < kSweepK / 2; ++u) {
-            const d2 v = __builtin_nontemporal_load(q2 + tid + u * kSweepThreads);
+            const d2 v = stream_load(q2 + tid + u * kSweepThreads);
             q[2 * u] = v.x;
             q[2 * u + 1] = v.y;
         }
+        stream_wait();
         for (int b = tid; b < kSweepBins; b += kSweepThreads) hist[b] = 0;
 #if MI_SWEEP_DYNAMIC
         if (tid == 0) next_chunk = 0;
@@ -593,7 +635,7 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
             d2 v;
             v.x = sq[sp[2 * u]];
             v.y = sq[sp[2 * u + 1]];
-            __builtin_nontemporal_store(v, o2 + tid + u * kSweepThreads);
+            stream_store(v, o2 + tid + u * kSweepThreads);
         }
         __syncthreads();   // the next tile's scatter reuses sq
     }
@@ -701,7 +743,7 @@ __global__ __launch_bounds__(kPipeThreads) void interp1_sweep_pipe_kernel(G1Dev 
 #pragma unroll
         for (int u = 0; u < kSweepK / 2; ++u) {
             if (u >= u0 && u < u1) {
-                const d2 v = __builtin_nontemporal_load(q2 + tid + u * kPipeGroup);
+                const d2 v = stream_load(q2 + tid + u * kPipeGroup);
                 q[2 * u] = v.x;
                 q[2 * u + 1] = v.y;
             }
@@ -715,7 +757,7 @@ __global__ __launch_bounds__(kPipeThreads) void interp1_sweep_pipe_kernel(G1Dev 
             d2 v;
             v.x = q[2 * u];
             v.y = q[2 * u + 1];
-            __builtin_nontemporal_store(v, o2 + tid + u * kPipeGroup);
+            stream_store(v, o2 + tid + u * kPipeGroup);
         }
     };
     for (int b = threadIdx.x; b < 2 * kSweepBins; b += kPipeThreads) (&hist[0][0])[b] = 0;
@@ -796,6 +838,7 @@ __global__ __launch_bounds__(kPipeThreads) void interp1_sweep_pipe_kernel(G1Dev 
         unsigned rank2[kSweepK / 2];         // rank inside the region (histogram ticket), two per register
 #pragma unroll
         for (int u = 0; u < kSweepK / 2; ++u) rank2[u] = 0;
+        stream_wait();
         if (act) {
             if (SCHED == 1) {
                 load_part(it + 1, 0, kSweepK / 4);
