@@ -133,6 +133,25 @@ __device__ __forceinline__ void wave_argmin(float& best, unsigned& idx)
     best = __uint_as_float(tmin);
 }
 
+// Experiment hook, compiled in with -DMI_EVOLVE_TIMING=1 only (scripts/gpu_evolve_phases.py): s_memtime ticks per wave,
+// summed over the grid, spent in [0] the Newton rounds, [1] arg-min + the uniform exponentials, [2] the state pass,
+// [3] the event bookkeeping; [4] events; [5], [6] 64-neuron slices of the state pass that reach will_fire's division / its
+// log and exp.
+#ifndef MI_EVOLVE_TIMING
+#define MI_EVOLVE_TIMING 0
+#endif
+#if MI_EVOLVE_TIMING
+__device__ unsigned long long g_evolve_ticks[8];
+#define MI_EV_STAMP(slot)                                              \
+    {                                                                  \
+        const unsigned long long tn_ = __builtin_readcyclecounter();   \
+        tacc[slot] += tn_ - tlast;                                     \
+        tlast = tn_;                                                   \
+    }
+#else
+#define MI_EV_STAMP(slot)
+#endif
+
 // ---- EvolveKernel (EventDrivenMap.cu:575-674): one wave64 per realisation ----
 // Neuron state lives in LDS, [wave][array][k*64 + lane]: every lane only ever
 // touches its own slots, so the event loop needs no barrier and the per-neuron
@@ -203,10 +222,16 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             }
         }
         unsigned events = 0;
+#if MI_EVOLVE_TIMING
+        unsigned long long tacc[4] = {0, 0, 0, 0};
+        unsigned nslow = 0, npow = 0;
+        unsigned long long tlast = __builtin_readcyclecounter();
+#endif
         while (crossed < full && now < two_T && events < M.max_events) {
             ++events;
             float best = base_t;
             unsigned idx = base_i;
+            MI_EV_STAMP(3)
             while (__any(pend != 0u)) {
                 if (pend != 0u) {
                     const unsigned k = (unsigned)__builtin_ctz(pend);
@@ -217,6 +242,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                     if (tau < best || (tau == best && i < idx)) { best = tau; idx = i; }
                 }
             }
+            MI_EV_STAMP(0)
             wave_argmin(best, idx);
             const float dt = best;
             // analytic state advance (EventDrivenMap.cu:612-617), fused with the firing test for the NEXT event
@@ -228,6 +254,10 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             }
             base_t = INFINITY;
             base_i = 0;
+#if MI_EVOLVE_TIMING
+            asm volatile("" : "+v"(e2u), "+v"(e3u));
+#endif
+            MI_EV_STAMP(1)
 #pragma unroll MI_EVOLVE_UNROLL
             for (unsigned k = 0; k < npl; ++k) {
                 const unsigned i = k * 64u + lane;
@@ -245,11 +275,16 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 sn = sn + bk * w_lds[dist & (kMaxGrid - 1)];
                 V[i] = vv;
                 S[i] = sn;
+#if MI_EVOLVE_TIMING
+                if (__any(i < M.N && !(sn < 0.0f))) ++nslow;       // slices that reach will_fire's division
+                if (__any(i < M.N && sn >= 0.0f)) ++npow;          // ... and its log/exp
+#endif
                 if (i < M.N) {
                     if (edm::will_fire<MATH>(M, vv, sn, bk)) pend |= (1u << k);
                     else if (base_t == INFINITY) { base_t = edm::kNever; base_i = i; }
                 }
             }
+            MI_EV_STAMP(2)
             now = now + dt;
             // which bump does the event belong to ([D3]: the reference's increment rule, :625-629)
             unsigned mi = 0;
@@ -276,6 +311,14 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 if (after) crossed += (1u << mi);
             }
         }
+#if MI_EVOLVE_TIMING
+        if (lane == 0) {
+            for (int j = 0; j < 4; ++j) atomicAdd(&g_evolve_ticks[j], tacc[j]);
+            atomicAdd(&g_evolve_ticks[4], (unsigned long long)events);
+            atomicAdd(&g_evolve_ticks[5], (unsigned long long)nslow);
+            atomicAdd(&g_evolve_ticks[6], (unsigned long long)npow);
+        }
+#endif
         // [spike][realisation] layout, EventDrivenMap.cu:661-668
 #pragma unroll
         for (int m = 0; m < NS; ++m) {
@@ -953,3 +996,14 @@ mi_status mi_edm_math_probe(mi_ctx* ctx, int math_mode, int op, const float* a_d
 }
 
 }  // extern "C"
+
+#if MI_EVOLVE_TIMING
+// experiment hook (not part of the ABI; only in -DMI_EVOLVE_TIMING=1 builds): read and clear the evolve phase ticks
+extern "C" int mi_debug_evolve_timing(unsigned long long* out8)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_evolve_ticks), sizeof(z)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_evolve_ticks), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif
