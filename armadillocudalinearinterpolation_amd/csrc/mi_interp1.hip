@@ -75,6 +75,9 @@ struct mi_grid1 {
     G1Dev d;
 };
 
+#ifndef MI_M3_TWO_LOOKUPS
+#define MI_M3_TWO_LOOKUPS 0   // mode 3, unordered queries: see eval_batch_from
+#endif
 #ifndef MI_INTERP1_COOP
 #define MI_INTERP1_COOP 0   // wavefront reuse of shared nodes through __shfl (mode 3, ordered queries): implemented,
                             // bit-exact, and slower than the three gathers it replaces (0.304 -> 0.366 ms per 1e8 sorted
@@ -224,22 +227,53 @@ __device__ __forceinline__ void eval_batch_from(const G1Dev& g, const double (&q
 #pragma unroll
         for (int k = 0; k < NQ; ++k) coop[k] = false;
 #endif
+        if constexpr (WIN) {
 #pragma unroll
-        for (int k = 0; k < NQ; ++k) {
-            if (coop[k]) continue;
-            if constexpr (WIN) nm[k] = load_node<LDSY>(ytab, max(l[k] - 1, 0));
-            n0[k] = load_node<LDSY>(ytab, l[k]);
-            n1[k] = load_node<LDSY>(ytab, l[k] + 1);        // index n is the padding node
-        }
-        if constexpr (!WIN) {   // fetch node G-1 only where it is needed (one dependent gather, no loop)
+            for (int k = 0; k < NQ; ++k) {
+                if (coop[k]) continue;
+                nm[k] = load_node<LDSY>(ytab, max(l[k] - 1, 0));
+                n0[k] = load_node<LDSY>(ytab, l[k]);
+                n1[k] = load_node<LDSY>(ytab, l[k] + 1);        // index n is the padding node
+            }
 #pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const bool down = qs[k] < n0[k].x;   // then l = G-1 >= 0 (G = 0 has X_0 <= q)
+                const d2 a = down ? nm[k] : n0[k], b = down ? n0[k] : n1[k];
+                out[k] = blend(a.x, a.y, b.x, b.y, qs[k]);
+            }
+        } else {
+            // Unordered queries (region sweep, 1e8 queries on the jittered 1e6-node grid): three eager gathers 1.25 ms;
+            // G and G+1 eager plus G-1 where the comparison with X_G asks for it 1.03 ms (shipped); G first and then one
+            // dependent gather of G-1 or G+1 (-DMI_M3_TWO_LOOKUPS=1: 2 lookups per query instead of 2.5) 1.08 ms.
+#if MI_M3_TWO_LOOKUPS
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) n0[k] = load_node<LDSY>(ytab, l[k]);
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const bool down = qs[k] < n0[k].x;
+                n1[k] = load_node<LDSY>(ytab, down ? max(l[k] - 1, 0) : l[k] + 1);
+            }
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const bool down = qs[k] < n0[k].x;
+                const d2 a = down ? n1[k] : n0[k], b = down ? n0[k] : n1[k];
+                out[k] = blend(a.x, a.y, b.x, b.y, qs[k]);
+            }
+#else
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                n0[k] = load_node<LDSY>(ytab, l[k]);
+                n1[k] = load_node<LDSY>(ytab, l[k] + 1);        // index n is the padding node
+            }
+#pragma unroll   // fetch node G-1 only where it is needed (one dependent gather, no loop)
             for (int k = 0; k < NQ; ++k) nm[k] = (qs[k] < n0[k].x) ? load_node<LDSY>(ytab, max(l[k] - 1, 0)) : n0[k];
-        }
 #pragma unroll
-        for (int k = 0; k < NQ; ++k) {
-            const bool down = qs[k] < n0[k].x;   // then l = G-1 >= 0 (G = 0 has X_0 <= q)
-            const d2 a = down ? nm[k] : n0[k], b = down ? n0[k] : n1[k];
-            out[k] = blend(a.x, a.y, b.x, b.y, qs[k]);
+            for (int k = 0; k < NQ; ++k) {
+                const bool down = qs[k] < n0[k].x;   // then l = G-1 >= 0 (G = 0 has X_0 <= q)
+                const d2 a = down ? nm[k] : n0[k], b = down ? n0[k] : n1[k];
+                out[k] = blend(a.x, a.y, b.x, b.y, qs[k]);
+            }
+#endif
         }
     } else {
         d2 n0[NQ], n1[NQ];
@@ -520,6 +554,15 @@ __device__ __forceinline__ void stream_wait() {}
 #define MI_SWEEP_DYNAMIC 0   // hand the gather chunks out dynamically: measured 0.711-0.716 vs 0.707-0.716 ms static -- no gain, off
 #endif
 constexpr size_t kSweepMinTilesPerCu = 2;   // profiles/r02_strong_scaling_shards.log: at 3 tiles per CU (1.25e7 queries) the sweep still wins 0.097 vs 0.135 ms
+#ifndef MI_SWEEP_M3_BATCH
+#define MI_SWEEP_M3_BATCH 4  // mode 3, pipelined form: queries per lane whose gathers are in flight together; 8 does not
+                             // fit the 128 registers of a 1024-lane workgroup (139-161 spilled: 1.59 ms against 1.03)
+#endif
+#ifndef MI_SWEEP_WIN
+#define MI_SWEEP_WIN 0       // mode 3: fetch node G-1 with G and G+1 (three independent gathers) instead of on demand:
+                             // 1.25 ms against 1.03 (profiles/r02_mode3_gather_variants.log)
+#endif
+constexpr bool kSweepWin = MI_SWEEP_WIN != 0;
 constexpr int kSweepThreads = MI_SWEEP_THREADS;
 constexpr int kSweepK = MI_SWEEP_K;                       // queries per lane per tile
 constexpr int kSweepTile = kSweepThreads * kSweepK;       // queries per tile (8 B of LDS each)
@@ -605,7 +648,7 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
                 const int p = (int)c * 256 + w * 64 + (tid & 63);
                 qq[w] = sq[rev ? kSweepTile - 1 - p : p];
             }
-            eval_batch<MODE, 4, FORMULA>(g, qq, rr, extrap);
+            eval_batch<MODE, 4, FORMULA, kSweepWin>(g, qq, rr, extrap);
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const int p = (int)c * 256 + w * 64 + (tid & 63);
@@ -621,7 +664,7 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
                 const int p = tid + (u + w) * kSweepThreads;
                 qq[w] = sq[rev ? kSweepTile - 1 - p : p];
             }
-            eval_batch<MODE, 4, FORMULA>(g, qq, rr, extrap);
+            eval_batch<MODE, 4, FORMULA, kSweepWin>(g, qq, rr, extrap);
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const int p = tid + (u + w) * kSweepThreads;
@@ -652,7 +695,7 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
         for (int u = 0; u < kSweepK; u += 4) {
             const double qq[4] = {q[u], q[u + 1], q[u + 2], q[u + 3]};
             double rr[4];
-            eval_batch<MODE, 4, FORMULA>(g, qq, rr, extrap);
+            eval_batch<MODE, 4, FORMULA, kSweepWin>(g, qq, rr, extrap);
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const size_t i = (size_t)tid + (size_t)(u + w) * kSweepThreads;
@@ -701,14 +744,15 @@ __device__ __forceinline__ void pipe_barrier()
 template <int MODE, int FORMULA>
 __device__ __forceinline__ void pipe_gather_rounds(const G1Dev& g, double* sq, int first, int stride, double extrap)
 {
+    constexpr int B = (MODE == 3) ? MI_SWEEP_M3_BATCH : 4;
 #pragma unroll 1
-    for (int r = 0; r < 2; ++r) {
-        double qq[4], rr[4];
+    for (int r = 0; r < 8 / B; ++r) {
+        double qq[B], rr[B];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) qq[w] = sq[first + (4 * r + w) * stride];
-        eval_batch<MODE, 4, FORMULA>(g, qq, rr, extrap);
+        for (int w = 0; w < B; ++w) qq[w] = sq[first + (B * r + w) * stride];
+        eval_batch<MODE, B, FORMULA, kSweepWin>(g, qq, rr, extrap);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) sq[first + (4 * r + w) * stride] = rr[w];
+        for (int w = 0; w < B; ++w) sq[first + (B * r + w) * stride] = rr[w];
     }
 }
 
@@ -946,7 +990,7 @@ __global__ __launch_bounds__(kPipeThreads) void interp1_sweep_pipe_kernel(G1Dev 
                 const size_t i = (size_t)tid + (size_t)(u + w) * kPipeGroup;
                 qq[w] = i < tail ? tq[i] : 0.0;
             }
-            eval_batch<MODE, 4, FORMULA>(g, qq, rr, extrap);
+            eval_batch<MODE, 4, FORMULA, kSweepWin>(g, qq, rr, extrap);
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const size_t i = (size_t)tid + (size_t)(u + w) * kPipeGroup;
