@@ -12,10 +12,17 @@ struct __attribute__((packed, aligned(8))) ypair { double a, b; };
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 __device__ __forceinline__ double blend(double xa, double ya, double xb, double yb, double q) {
     const double a = q - xa, b = xb - q; const double w = (a > 0.0) ? a / (a + b) : 0.0; return (1.0 - w) * ya + w * yb; }
+#ifdef EXP_FOLD
+__constant__ int g_fold = 0x7fffffff;   // exp_sweep6: the gather address is folded into a smaller footprint (index & g_fold)
+#endif
 template <int GATHER>
 __device__ __forceinline__ double evalq(const double* __restrict__ y, int n, double dx, double inv_dx, double q) {
     int i = (int)(q * inv_dx); i = min(max(i, 0), n - 2);
     ypair yp;
+#ifdef EXP_FOLD
+    if (GATHER == 1) yp = *(const ypair*)(y + (i & g_fold));
+    else
+#endif
     if (GATHER == 1) yp = *(const ypair*)(y + i);                      // one unaligned 16-B load
     else if (GATHER == 2) { yp.a = y[i]; yp.b = y[i + 1]; }            // two 8-B loads
     else if (GATHER == 3) { const d2 v = *(const d2*)(y + 2 * (size_t)i); yp.a = v.x; yp.b = v.y; }   // aligned pair table
