@@ -545,6 +545,15 @@ class Group:
         check(self._L.mi_group_grid1_create(self._h, _ptr(X), _ptr(Y), X.size, 1 if sanitise else 0, C.byref(t)))
         return GroupGrid1(self, t)
 
+    def grid2(self, x, y, z, compact=False):
+        """2-D table replicated on every device; z is (len(y), len(x))"""
+        x, y = _np64(x), _np64(y)
+        zc = Grid2._colmajor(z, y.size, x.size)
+        t = C.c_void_p()
+        check(self._L.mi_group_grid2_create(self._h, _ptr(x), x.size, _ptr(y), y.size, _ptr(zc),
+                                            MI_GRID2_COMPACT if compact else 0, C.byref(t)))
+        return GroupGrid2(self, t)
+
     def edm(self, parameters, noReal, **overrides):
         return GroupEventDrivenMap(self, parameters, noReal, **overrides)
 
@@ -588,6 +597,45 @@ class GroupGrid1:
     def close(self):
         if getattr(self, "_h", None):
             self._L.mi_group_grid1_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GroupGrid2:
+    def __init__(self, group, h):
+        self._g, self._L, self._h = group, group._L, h
+
+    def interp_host(self, xq, yq, extrap=math.nan):
+        """host arrays in, host array out; the scattered queries are sharded over the group's devices"""
+        xq, yq = _np64(xq), _np64(yq)
+        if xq.size != yq.size:
+            raise ValueError("xq and yq must have the same number of elements")
+        out = np.empty_like(xq)
+        check(self._L.mi_group_interp2_f64_host(self._g._h, self._h, _ptr(xq), _ptr(yq), _ptr(out), xq.size, float(extrap)))
+        return out
+
+    def interp_dev(self, xq_shards, yq_shards, extrap=math.nan, gather=False):
+        """device-resident shards (one pair of float64 tensors per group member, equal sizes)"""
+        torch = _torch()
+        P, n = len(self._g), int(xq_shards[0].numel())
+        assert len(xq_shards) == P and len(yq_shards) == P
+        assert all(int(t.numel()) == n for t in xq_shards) and all(int(t.numel()) == n for t in yq_shards)
+        outs = [torch.empty_like(t) for t in xq_shards]
+        full = [torch.empty(P * n, dtype=torch.float64, device=t.device) for t in xq_shards] if gather else None
+        arr = lambda ts: (C.c_void_p * P)(*[t.data_ptr() for t in ts])  # noqa: E731
+        check(self._L.mi_group_interp2_f64_dev(self._g._h, self._h, arr(xq_shards), arr(yq_shards), arr(outs), n,
+                                               float(extrap), arr(full) if gather else None))
+        self._g.synchronize()
+        return (outs, full) if gather else outs
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mi_group_grid2_destroy(self._h)
             self._h = None
 
     def __del__(self):

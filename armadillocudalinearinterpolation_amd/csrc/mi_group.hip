@@ -50,6 +50,11 @@ struct mi_group_grid1 {
     std::vector<mi_grid1*> grid;
 };
 
+struct mi_group_grid2 {
+    mi_group* g;
+    std::vector<mi_grid2*> grid;
+};
+
 struct mi_group_edm {
     mi_group* g;
     mi_edm_params total;
@@ -103,6 +108,8 @@ mi_status bind_rccl(mi_group* g)
     } while (0)
 
 }  // namespace
+
+static mi_status gather_shards(mi_group* g, double* const* part_dev, double* const* gathered_dev, size_t n_per_shard);
 
 extern "C" {
 
@@ -242,31 +249,10 @@ mi_status mi_group_interp1_f64_dev(mi_group* g, const mi_group_grid1* t, const d
         if (gathered_dev && !g->distinct) MI_HIP(g->ctx[r], hipEventRecord(g->done[r], g->ctx[r]->stream));
     }
     if (!gathered_dev || nq_per_shard == 0) return MI_OK;
-    if (g->distinct) {
-        // every device receives the P shards, shard s at offset s * nq_per_shard (in place when yq_dev[r] already
-        // points there): one all-gather over xGMI, enqueued behind each device's kernel on its own stream
-        MI_NCCL(g, g->GroupStart());
-        for (size_t r = 0; r < P; ++r) {
-            const ncclResult_t rc = g->AllGather(yq_dev[r], gathered_dev[r], nq_per_shard, mi_ncclFloat64, g->comms[r], g->ctx[r]->stream);
-            if (rc != 0) {
-                (void)g->GroupEnd();
-                return mi::fail(nullptr, MI_ERR_HIP, "ncclAllGather failed: %s", g->GetErrorString ? g->GetErrorString(rc) : "?");
-            }
-        }
-        MI_NCCL(g, g->GroupEnd());
-        return MI_OK;
-    }
-    // rehearsal group (a device named more than once): the same data movement with device-to-device copies
-    for (size_t r = 0; r < P; ++r) {
-        MI_HIP(g->ctx[r], hipSetDevice(g->dev[r]));
-        for (size_t s = 0; s < P; ++s) {
-            double* dst = gathered_dev[r] + s * nq_per_shard;
-            if (dst == yq_dev[s]) continue;
-            MI_HIP(g->ctx[r], hipStreamWaitEvent(g->ctx[r]->stream, g->done[s], 0));
-            MI_HIP(g->ctx[r], hipMemcpyAsync(dst, yq_dev[s], nq_per_shard * sizeof(double), hipMemcpyDeviceToDevice, g->ctx[r]->stream));
-        }
-    }
-    return MI_OK;
+    // every device receives the P shards, shard s at offset s * nq_per_shard (in place when yq_dev[r] already points
+    // there): one all-gather over xGMI, enqueued behind each device's kernel on its own stream -- or, in a rehearsal
+    // group (a device named more than once), the same data movement with device-to-device copies
+    return gather_shards(g, yq_dev, gathered_dev, nq_per_shard);
 }
 
 mi_status mi_group_interp1_f64_host(mi_group* g, const mi_group_grid1* t, const double* xq, double* yq, size_t nq, double extrap)
@@ -308,6 +294,131 @@ mi_status mi_group_interp1_f64_host(mi_group* g, const mi_group_grid1* t, const 
     if (st != MI_OK) return st;
     if (herr != hipSuccess) return mi::fail(nullptr, MI_ERR_HIP, "mi_group_interp1_f64_host: copy failed: %s", hipGetErrorString(herr));
     if (esync != hipSuccess) return mi::fail(nullptr, MI_ERR_HIP, "mi_group_interp1_f64_host: %s", hipGetErrorString(esync));
+    return MI_OK;
+}
+
+// ---- 2-D table interpolation (BASELINE config 3 over several GPUs: scattered query shards, the table replicated) ------
+
+mi_status mi_group_grid2_create(mi_group* g, const double* x, size_t nx, const double* y, size_t ny, const double* z,
+                                unsigned flags, mi_group_grid2** out)
+{
+    MI_REQUIRE(nullptr, g && out, "mi_group_grid2_create: NULL argument");
+    *out = nullptr;
+    MI_REQUIRE(nullptr, (flags & MI_GRID_DEVICE_PTRS) == 0, "mi_group_grid2_create: the table is given in host memory (it is replicated on every device)");
+    mi_group_grid2* t = new (std::nothrow) mi_group_grid2();
+    if (!t) return mi::fail(nullptr, MI_ERR_NOMEM, "mi_group_grid2_create: out of host memory");
+    t->g = g;
+    for (size_t r = 0; r < g->ctx.size(); ++r) {
+        mi_grid2* gr = nullptr;
+        const mi_status st = mi_grid2_create(g->ctx[r], x, nx, y, ny, z, flags, &gr);
+        if (st != MI_OK) {
+            mi_group_grid2_destroy(t);
+            return st;
+        }
+        t->grid.push_back(gr);
+    }
+    *out = t;
+    return MI_OK;
+}
+
+mi_status mi_group_grid2_destroy(mi_group_grid2* t)
+{
+    if (!t) return MI_OK;
+    for (mi_grid2* gr : t->grid) mi_grid2_destroy(gr);
+    delete t;
+    return MI_OK;
+}
+
+// results of every shard to every device: RCCL all-gather (distinct devices) or device-to-device copies (rehearsal group)
+static mi_status gather_shards(mi_group* g, double* const* part_dev, double* const* gathered_dev, size_t n_per_shard)
+{
+    const size_t P = g->ctx.size();
+    if (g->distinct) {
+        MI_NCCL(g, g->GroupStart());
+        for (size_t r = 0; r < P; ++r) {
+            const ncclResult_t rc = g->AllGather(part_dev[r], gathered_dev[r], n_per_shard, mi_ncclFloat64, g->comms[r], g->ctx[r]->stream);
+            if (rc != 0) {
+                (void)g->GroupEnd();
+                return mi::fail(nullptr, MI_ERR_HIP, "ncclAllGather failed: %s", g->GetErrorString ? g->GetErrorString(rc) : "?");
+            }
+        }
+        MI_NCCL(g, g->GroupEnd());
+        return MI_OK;
+    }
+    for (size_t r = 0; r < P; ++r) {
+        MI_HIP(g->ctx[r], hipSetDevice(g->dev[r]));
+        for (size_t s = 0; s < P; ++s) {
+            double* dst = gathered_dev[r] + s * n_per_shard;
+            if (dst == part_dev[s]) continue;
+            MI_HIP(g->ctx[r], hipStreamWaitEvent(g->ctx[r]->stream, g->done[s], 0));
+            MI_HIP(g->ctx[r], hipMemcpyAsync(dst, part_dev[s], n_per_shard * sizeof(double), hipMemcpyDeviceToDevice, g->ctx[r]->stream));
+        }
+    }
+    return MI_OK;
+}
+
+mi_status mi_group_interp2_f64_dev(mi_group* g, const mi_group_grid2* t, const double* const* xq_dev, const double* const* yq_dev,
+                                   double* const* zq_dev, size_t nq_per_shard, double extrap, double* const* gathered_dev)
+{
+    MI_REQUIRE(nullptr, g && t && xq_dev && yq_dev && zq_dev, "mi_group_interp2_f64_dev: NULL argument");
+    MI_REQUIRE(nullptr, t->g == g && t->grid.size() == g->ctx.size(), "mi_group_interp2_f64_dev: the table belongs to another group");
+    const size_t P = g->ctx.size();
+    if (gathered_dev && g->distinct) {
+        const mi_status st = bind_rccl(g);
+        if (st != MI_OK) return st;
+    }
+    for (size_t r = 0; r < P; ++r) {
+        const mi_status st = mi_interp2_f64_dev(g->ctx[r], t->grid[r], xq_dev[r], yq_dev[r], zq_dev[r], nq_per_shard, extrap);
+        if (st != MI_OK) return st;
+        if (gathered_dev && !g->distinct) MI_HIP(g->ctx[r], hipEventRecord(g->done[r], g->ctx[r]->stream));
+    }
+    if (!gathered_dev || nq_per_shard == 0) return MI_OK;
+    return gather_shards(g, zq_dev, gathered_dev, nq_per_shard);
+}
+
+mi_status mi_group_interp2_f64_host(mi_group* g, const mi_group_grid2* t, const double* xq, const double* yq, double* zq, size_t nq,
+                                    double extrap)
+{
+    MI_REQUIRE(nullptr, g && t, "mi_group_interp2_f64_host: NULL argument");
+    MI_REQUIRE(nullptr, t->g == g && t->grid.size() == g->ctx.size(), "mi_group_interp2_f64_host: the table belongs to another group");
+    if (nq == 0) return MI_OK;
+    MI_REQUIRE(nullptr, xq && yq && zq, "mi_group_interp2_f64_host: NULL query/result pointer");
+    const int P = (int)g->ctx.size();
+    const bool pin_x = mi::pin_host(xq, nq * sizeof(double)), pin_y = mi::pin_host(yq, nq * sizeof(double)),
+               pin_z = mi::pin_host(zq, nq * sizeof(double));
+    mi_status st = MI_OK;
+    hipError_t herr = hipSuccess;
+    for (int r = 0; r < P && st == MI_OK && herr == hipSuccess; ++r) {
+        size_t lo, hi;
+        mi_shard_bounds(nq, r, P, &lo, &hi);
+        if (hi == lo) continue;
+        mi_ctx* c = g->ctx[r];
+        herr = hipSetDevice(g->dev[r]);
+        if (herr != hipSuccess) break;
+        const size_t bytes = (hi - lo) * sizeof(double);
+        for (int k = 0; k < 3 && st == MI_OK; ++k) st = mi::ensure_scratch(c, k, bytes);
+        if (st != MI_OK) break;
+        herr = hipMemcpyAsync(c->scratch[0], xq + lo, bytes, hipMemcpyHostToDevice, c->stream);
+        if (herr != hipSuccess) break;
+        herr = hipMemcpyAsync(c->scratch[1], yq + lo, bytes, hipMemcpyHostToDevice, c->stream);
+        if (herr != hipSuccess) break;
+        st = mi_interp2_f64_dev(c, t->grid[r], (const double*)c->scratch[0], (const double*)c->scratch[1], (double*)c->scratch[2],
+                                hi - lo, extrap);
+        if (st != MI_OK) break;
+        herr = hipMemcpyAsync(zq + lo, c->scratch[2], bytes, hipMemcpyDeviceToHost, c->stream);
+    }
+    hipError_t esync = hipSuccess;
+    for (int r = 0; r < P; ++r) {   // drain every stream before the ranges are released, on success or error
+        (void)hipSetDevice(g->dev[r]);
+        const hipError_t e = hipStreamSynchronize(g->ctx[r]->stream);
+        if (e != hipSuccess && esync == hipSuccess) esync = e;
+    }
+    if (pin_x) mi::unpin_host(xq);
+    if (pin_y) mi::unpin_host(yq);
+    if (pin_z) mi::unpin_host(zq);
+    if (st != MI_OK) return st;
+    if (herr != hipSuccess) return mi::fail(nullptr, MI_ERR_HIP, "mi_group_interp2_f64_host: copy failed: %s", hipGetErrorString(herr));
+    if (esync != hipSuccess) return mi::fail(nullptr, MI_ERR_HIP, "mi_group_interp2_f64_host: %s", hipGetErrorString(esync));
     return MI_OK;
 }
 

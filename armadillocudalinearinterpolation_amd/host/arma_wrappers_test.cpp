@@ -57,6 +57,13 @@ int main(int argc, char** argv)
     }
     mi355::interp2(xg, yg, Z, xq, yq, ZI);
     dump(out + "/w_interp2.bin", ZI);
+    {   // the same over a device group (GPU 0 named twice: two query shards)
+        mi355::DeviceGroup grp2(std::vector<int>{0, 0});
+        mi355::GroupInterp2Table g2(grp2, xg, yg, Z);
+        arma::vec ZG;
+        g2(xq, yq, ZG);
+        dump(out + "/w_group_interp2.bin", ZG);
+    }
     // the reference's own interpolation on host vectors (known answer of SURVEY 8c + a small batch)
     arma::fvec t0(4), t1(4), xr;
     std::vector<uint16_t> i0 = {512, 100, 1023, 0}, i1 = {514, 101, 1023, 1};

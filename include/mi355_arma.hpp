@@ -171,4 +171,31 @@ class GroupInterp1Table {
     mi_group_grid1* t_;
 };
 
+// Scattered bilinear interpolation (BASELINE config 3) over the group: Z = arma::mat(Y.n_elem, X.n_elem) replicated, the
+// query pairs sharded; one result per pair, as mi355::interp2.
+class GroupInterp2Table {
+  public:
+    GroupInterp2Table(DeviceGroup& grp, const arma::vec& X, const arma::vec& Y, const arma::mat& Z) : grp_(grp), t_(nullptr)
+    {
+        if (Z.n_rows != Y.n_elem || Z.n_cols != X.n_elem) throw std::invalid_argument("interp2(): Z must be Y.n_elem x X.n_elem");
+        check(mi_group_grid2_create(grp_.get(), X.memptr(), X.n_elem, Y.memptr(), Y.n_elem, Z.memptr(), 0u, &t_), nullptr,
+              "mi_group_grid2_create");
+    }
+    ~GroupInterp2Table() { mi_group_grid2_destroy(t_); }
+    GroupInterp2Table(const GroupInterp2Table&) = delete;
+    GroupInterp2Table& operator=(const GroupInterp2Table&) = delete;
+    void operator()(const arma::vec& XI, const arma::vec& YI, arma::vec& ZI,
+                    double extrap_val = std::numeric_limits<double>::quiet_NaN()) const
+    {
+        if (XI.n_elem != YI.n_elem) throw std::invalid_argument("interp2(): XI and YI must have the same number of elements");
+        ZI.set_size(XI.n_elem);
+        check(mi_group_interp2_f64_host(grp_.get(), t_, XI.memptr(), YI.memptr(), ZI.memptr(), XI.n_elem, extrap_val), nullptr,
+              "mi_group_interp2_f64_host");
+    }
+
+  private:
+    DeviceGroup& grp_;
+    mi_group_grid2* t_;
+};
+
 }  // namespace mi355

@@ -335,6 +335,18 @@ mi_status mi_group_interp1_f64_dev(mi_group* g, const mi_group_grid1* t, const d
                                    double* const* yq_dev, size_t nq_per_shard, double extrap_val,
                                    double* const* gathered_dev);
 
+/* 2-D table (BASELINE.json config 3) replicated on every device of the group; arguments as mi_grid2_create (host
+ * pointers), the scattered queries sharded exactly as for the 1-D table. */
+typedef struct mi_group_grid2 mi_group_grid2;
+mi_status mi_group_grid2_create(mi_group* g, const double* x, size_t nx, const double* y, size_t ny, const double* z,
+                                unsigned flags, mi_group_grid2** out);
+mi_status mi_group_grid2_destroy(mi_group_grid2* t);
+mi_status mi_group_interp2_f64_host(mi_group* g, const mi_group_grid2* t, const double* xq, const double* yq, double* zq,
+                                    size_t nq, double extrap_val);
+mi_status mi_group_interp2_f64_dev(mi_group* g, const mi_group_grid2* t, const double* const* xq_dev,
+                                   const double* const* yq_dev, double* const* zq_dev, size_t nq_per_shard,
+                                   double extrap_val, double* const* gathered_dev);
+
 /* EventDrivenMap with the realisations sharded over the group: p->n_real is the TOTAL (>= group size); shard r evolves
  * realisations [lo_r, hi_r) = mi_shard_bounds(n_real, r, P) with real_offset = p->real_offset + lo_r, so the per-neuron
  * draws -- and therefore every result -- are those of the unsharded ensemble. */

@@ -74,6 +74,7 @@ def test_public_header_is_plain_c99(tmp_path):
                    "static fn group_api[] = { (fn)mi_group_create, (fn)mi_group_destroy, (fn)mi_group_size,\n"
                    "  (fn)mi_group_ctx, (fn)mi_group_synchronize, (fn)mi_group_set_reduce, (fn)mi_group_grid1_create,\n"
                    "  (fn)mi_group_grid1_destroy, (fn)mi_group_interp1_f64_host, (fn)mi_group_interp1_f64_dev,\n"
+                   "  (fn)mi_group_grid2_create, (fn)mi_group_grid2_destroy, (fn)mi_group_interp2_f64_host, (fn)mi_group_interp2_f64_dev,\n"
                    "  (fn)mi_group_edm_create, (fn)mi_group_edm_destroy, (fn)mi_group_edm_set_params,\n"
                    "  (fn)mi_group_edm_compute_f, (fn)mi_group_edm_shard, (fn)mi_group_edm_shard_bounds };\n"
                    "int main(void) { mi_edm_params p; size_t lo, hi; double z[3] = {0.3, 0.7, 1.4}, f[3], sc[MI_EDM_PARTIAL_LEN(3)] = {3, 3, 3, 2, 9, 9, 9};\n"

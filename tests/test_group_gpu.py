@@ -43,6 +43,34 @@ def test_group_interp1_host_and_device_shards(mi_ctx, devices):
     grp.close()
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_group_interp2_host_and_device_shards(mi_ctx, devices):
+    """BASELINE config 3's shape over a group: scattered bilinear queries, table replicated, query shards."""
+    import torch
+    import armadillocudalinearinterpolation_amd as mi
+    nx, ny = 193, 157
+    x = np.linspace(-1.0, 2.0, nx)
+    y = np.cumsum(0.5 + oracle.splitmix_uniform(3, ny))             # non-uniform axis
+    zz = np.sin(3 * y)[:, None] * np.cos(2 * x)[None, :] + 0.1 * x[None, :] * y[:, None]
+    nq = 200_003
+    xq = oracle.splitmix_uniform(8, nq) * 3.2 - 1.1                  # some out of range
+    yq = y[0] + oracle.splitmix_uniform(9, nq) * (y[-1] - y[0]) * 1.05 - 0.02
+    ref = oracle.interp2_bilinear(x, y, zz, xq, yq)
+    grp = mi.Group(devices)
+    tab = grp.grid2(x, y, zz)
+    assert np.array_equal(tab.interp_host(xq, yq), ref, equal_nan=True)
+    assert np.array_equal(tab.interp_host(xq, yq, extrap=7.0), oracle.interp2_bilinear(x, y, zz, xq, yq, extrap=7.0))
+    P, n = len(devices), 50_001
+    xs = [torch.from_numpy(xq[r * n:(r + 1) * n].copy()).cuda() for r in range(P)]
+    ys = [torch.from_numpy(yq[r * n:(r + 1) * n].copy()).cuda() for r in range(P)]
+    outs, full = tab.interp_dev(xs, ys, gather=True)
+    for r in range(P):
+        assert np.array_equal(outs[r].cpu().numpy(), ref[r * n:(r + 1) * n], equal_nan=True)
+        assert np.array_equal(full[r].cpu().numpy(), ref[:P * n], equal_nan=True)
+    tab.close()
+    grp.close()
+
+
 def test_shard_bounds_match_python(mi_ctx):
     import armadillocudalinearinterpolation_amd as mi
     from armadillocudalinearinterpolation_amd import sharding

@@ -103,6 +103,7 @@ def test_arma_wrappers_match_oracle(tmp_path):
     ref2 = oracle.interp2_bilinear(xg, yg, Z, xq, yq)
     assert np.array_equal(np.isnan(got), np.isnan(ref2))
     assert np.nanmax(np.abs(got - ref2)) < 1e-14
+    assert np.array_equal(rd("w_group_interp2.bin"), got, equal_nan=True)       # the same pairs sharded over a device group
 
 
 def _oracle_f(p, u, seed_ind=None, n_real_reference_mean=0):
