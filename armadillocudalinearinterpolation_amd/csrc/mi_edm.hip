@@ -158,7 +158,8 @@ __device__ unsigned long long g_evolve_ticks[8];
 // loop stays rolled (few VGPRs -> 3 workgroups per CU at N = 1024).
 // LDS per workgroup: w[1024] + 4 waves * (2 or 3) arrays * npl*64 floats.
 // NS: compile-time bound of the per-bump loops (3 = the reference's noSpikes, else kMaxSpikes)
-template <int MATH, bool HETERO, int NS>
+// UDIV: divisions by the homogeneous model's wave-uniform divisors through edm::div_by's five-operation exact quotient
+template <int MATH, bool HETERO, int NS, bool UDIV>
 __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, SpikeSeeds sd,
                                                               const float* __restrict__ v0,
                                                               const float* __restrict__ s0,
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             const unsigned i = k * 64u + lane;
             if (i < M.N) {
                 const float bk = HETERO ? B[i] : M.beta_mean;
-                if (edm::will_fire<MATH>(M, V[i], S[i], bk)) pend |= (1u << k);
+                if (edm::will_fire<MATH, UDIV && !HETERO>(M, V[i], S[i], bk)) pend |= (1u << k);
                 else if (base_t == INFINITY) { base_t = edm::kNever; base_i = i; }
             }
         }
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                     pend &= pend - 1u;
                     const unsigned i = k * 64u + lane;
                     const float bk = HETERO ? B[i] : M.beta_mean;
-                    const float tau = edm::newton_time<MATH>(M, V[i], S[i], bk);
+                    const float tau = edm::newton_time<MATH, UDIV && !HETERO>(M, V[i], S[i], bk);
                     if (tau < best || (tau == best && i < idx)) { best = tau; idx = i; }
                 }
             }
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 const float e3 = HETERO ? edm::expf_<MATH>(-bk * dt) : e3u;
                 const float so = S[i];
                 float vv = V[i] * e1;
-                vv = vv + (M.I * (1.0f - e1) + edm::div_<MATH>(so * e1, 1.0f - bk) * (e2 - 1.0f));
+                vv = vv + (M.I * (1.0f - e1) + edm::div_by<MATH, UDIV && !HETERO>(so * e1, 1.0f - bk) * (e2 - 1.0f));
                 // reset of the neuron that fired (:615 multiplies every v by (tid != index)): x*1 == x, so only
                 // the slice that holds idx needs the multiply
                 if (k == (idx >> 6)) vv = vv * ((i != idx) ? 1.0f : 0.0f);
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 if (__any(i < M.N && sn >= 0.0f)) ++npow;          // ... and its log/exp
 #endif
                 if (i < M.N) {
-                    if (edm::will_fire<MATH>(M, vv, sn, bk)) pend |= (1u << k);
+                    if (edm::will_fire<MATH, UDIV && !HETERO>(M, vv, sn, bk)) pend |= (1u << k);
                     else if (base_t == INFINITY) { base_t = edm::kNever; base_i = i; }
                 }
             }
@@ -531,6 +532,8 @@ __global__ void math_probe_kernel(int op, const float* a, const float* b, float*
         case 0: r = edm::expf_<MATH>(a[i]); break;
         case 1: r = edm::logf_<MATH>(a[i]); break;
         case 2: r = edm::powf_<MATH>(a[i], b[i]); break;
+        case 4: r = edm::div_by<MATH, true>(a[i], b[0]); break;    // quotient by a wave-uniform divisor (b[0])
+        case 5: r = a[i] / b[0]; break;                           // the IEEE expansion, for comparison
         default: r = edm::erfinvf_<MATH>(a[i]); break;
     }
     out[i] = r;
@@ -708,11 +711,17 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd)
     }
     const bool three = e->p.n_spikes <= 3;
     if (wpr == 1) {
-#define MI_EVOLVE(H, NS)                                                                                          \
-    hipLaunchKernelGGL((evolve_kernel<MATH, H, NS>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, M, sd, \
+#define MI_EVOLVE(H, NS, UD)                                                                                      \
+    hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, UD>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, M, sd, \
                        e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept)
-        if (hetero) { if (three) MI_EVOLVE(true, 3); else MI_EVOLVE(true, kMaxSpikes); }
-        else { if (three) MI_EVOLVE(false, 3); else MI_EVOLVE(false, kMaxSpikes); }
+        // The exact quotient by uniform divisors pays where there are waves enough to hide its (longer) dependent chain:
+        // the LDS leaving six or more per SIMD (N <= 640) and the launch bringing three or more.  N = 512: R = 16384
+        // 10.25 -> 9.00 ms, R = 4000 3.10 -> 2.91 ms, but R = 1000 (one wave per SIMD) 1.59 -> 2.10 ms.
+        const unsigned cus = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256);
+        const bool udiv = MATH == 0 && !hetero && per_cu >= 6 && Reff >= cus * 12u && getenv("MI_EDM_NO_UNIFORM_DIV") == nullptr;
+        if (hetero) { if (three) MI_EVOLVE(true, 3, false); else MI_EVOLVE(true, kMaxSpikes, false); }
+        else if (udiv) { if (three) MI_EVOLVE(false, 3, true); else MI_EVOLVE(false, kMaxSpikes, true); }
+        else { if (three) MI_EVOLVE(false, 3, false); else MI_EVOLVE(false, kMaxSpikes, false); }
 #undef MI_EVOLVE
     } else {
         const unsigned bt = 64u * (unsigned)wpr;
@@ -980,7 +989,8 @@ mi_status mi_edm_last_timings(mi_edm* e, float ms[4])
     return MI_OK;
 }
 
-// test hook: run the device math routines on arrays (op: 0 exp, 1 log, 2 pow, 3 erfinv)
+// test hook: run the device math routines on arrays (op: 0 exp, 1 log, 2 pow, 3 erfinv, 4 a / b[0] as the kernels
+// divide by a wave-uniform divisor, 5 a / b[0] as IEEE division)
 mi_status mi_edm_math_probe(mi_ctx* ctx, int math_mode, int op, const float* a_dev, const float* b_dev,
                             float* out_dev, size_t n)
 {

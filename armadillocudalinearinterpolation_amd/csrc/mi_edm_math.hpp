@@ -163,14 +163,55 @@ MI_HD float div_(float a, float b)
     return a / b;
 }
 
+// a / c for a divisor c that is the same in every lane and in every call of a launch (UNI; 1 - beta, beta - 1, vth - I of
+// the homogeneous model), EXACT mode on the device: the IEEE quotient without the eleven-instruction expansion of `/`
+// (v_div_scale x2, v_rcp, five fma, v_div_fmas, v_div_fixup; the pipeline has some 45 divisions per event, 26 of them by
+// such a divisor).  With y = RN(1/c) -- an IEEE division that the compiler hoists out of every loop -- q0 = RN(a y) is
+// within 1.5 ulp of a/c; one Newton step q1 = RN(q0 + RN(a - c q0) y) (the residual is exact by fma) is a faithful
+// rounding of a/c, and by Markstein's theorem (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic,
+// sec. 4.7) a second step from a faithful quotient with y = RN(1/c) gives RN(a/c) itself: five multiply/fma.  The
+// theorem wants no overflow and exact (possibly subnormal) residuals: |c| in [2^-20, 2^20] and |a| in [2^-100, 2^100].
+// A zero, infinite or NaN numerator gives its IEEE result already as a * y (signed zero, signed infinity, NaN); a finite
+// numerator outside the range takes the IEEE expansion (the wave skips it when no lane needs it; none did in 5e9
+// divisions of ComputeF at the reference's parameters), and so does a divisor outside its range.
+// Checked against `/` bit for bit by tests/test_edm_gpu.py::test_uniform_divisor_quotient_is_the_ieee_quotient.
+// Used where it pays: with eight waves per SIMD (N <= 512, the reference's Driver.cu) Evolve is 13 % faster with it; at
+// N = 1024 (four waves per SIMD) the guard costs what the division saves (profiles/r02_edm_evolve_phases.log).
+template <int MATH, bool UNI>
+MI_HD float div_by(float a, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (MATH == 1) return a * __builtin_amdgcn_rcpf(c);
+    if constexpr (UNI) {
+        if (fabsf(c) >= 0x1.0p-20f && fabsf(c) <= 0x1.0p+20f) {      // (uniform)
+            const float rc = 1.0f / c;
+            const float aa = fabsf(a);
+            const float q0 = a * rc;
+            float q = fmaf(fmaf(-c, q0, a), rc, q0);
+            q = fmaf(fmaf(-c, q, a), rc, q);
+            const bool in_range = aa >= 0x1.0p-100f && aa <= 0x1.0p+100f;   // false for NaN
+            const bool trivial = !(aa > 0.0f) || aa == INFINITY;            // zero, NaN, infinity
+            q = in_range ? q : q0;
+            const bool hard = !in_range && !trivial;
+            if (__any(hard)) {
+                const float qi = a / c;
+                q = hard ? qi : q;
+            }
+            return q;
+        }
+    }
+#endif
+    return a / c;
+}
+
 // fun/dfun, EventDrivenMap.cu:544-552, sharing e1 = exp(-t), e2 = exp((1-beta) t)
-template <int MATH>
+template <int MATH, bool UNI = false>
 MI_HD FdF fun_dfun_e(const Model& M, float e1, float e2, float v, float s, float beta)
 {
     const float se = s * e1;
     FdF r;
-    r.f = ((v * e1 + M.I * (1.0f - e1)) + div_<MATH>(se, 1.0f - beta) * (e2 - 1.0f)) - M.vth;
-    r.df = ((M.I * e1 - v * e1) + se * e2) + div_<MATH>(se * (e2 - 1.0f), beta - 1.0f);
+    r.f = ((v * e1 + M.I * (1.0f - e1)) + div_by<MATH, UNI>(se, 1.0f - beta) * (e2 - 1.0f)) - M.vth;
+    r.df = ((M.I * e1 - v * e1) + se * e2) + div_by<MATH, UNI>(se * (e2 - 1.0f), beta - 1.0f);
     return r;
 }
 
@@ -182,7 +223,7 @@ MI_HD FdF fun_dfun_e(const Model& M, float e1, float e2, float v, float s, float
 // At t = 0 both exponentials are exactly 1 (expf_(+-0) == 1), so the first evaluation needs no exp.
 constexpr float kNever = 100.0f;
 
-template <int MATH>
+template <int MATH, bool UNI = false>
 MI_HD bool will_fire(const Model& M, float v0, float s0, float beta)
 {
     const float gap = M.vth - M.I;
@@ -190,23 +231,23 @@ MI_HD bool will_fire(const Model& M, float v0, float s0, float beta)
     // With 0 < gap <= 1 the quotient s0/gap cannot underflow to -0, so s0 < 0 already decides it (no division);
     // the inhibitory surround puts most of the ring in this case, 64 contiguous neurons per wave step.
     if (gap > 0.0f && gap <= 1.0f && s0 < 0.0f) return false;
-    const float ratio = div_<MATH>(s0, gap);
+    const float ratio = div_by<MATH, UNI>(s0, gap);   // (gap is always uniform; UNI only says whether the kernel opted in)
     if (!(ratio >= 0.0f)) return false;
     const float pw = powf_<MATH>(ratio, div_<MATH>(1.0f, beta));
     const float thr = (M.vth * pw + M.I * (1.0f - pw)) - div_<MATH>(gap, beta - 1.0f) * (ratio - pw);
     return v0 > thr;
 }
 
-template <int MATH>
+template <int MATH, bool UNI = false>
 MI_HD float newton_time(const Model& M, float v0, float s0, float beta)
 {
     float t = 0.0f;
-    FdF r = fun_dfun_e<MATH>(M, 1.0f, 1.0f, v0, s0, beta);
+    FdF r = fun_dfun_e<MATH, UNI>(M, 1.0f, 1.0f, v0, s0, beta);
     float f = r.f, df = r.df;
     uint32_t counter = 0;
     while ((fabsf(f) > M.tol_f) && (counter < M.max_iter)) {
         t = t - div_<MATH>(f, df);
-        r = fun_dfun_e<MATH>(M, expf_<MATH>(-t), expf_<MATH>((1.0f - beta) * t), v0, s0, beta);
+        r = fun_dfun_e<MATH, UNI>(M, expf_<MATH>(-t), expf_<MATH>((1.0f - beta) * t), v0, s0, beta);
         f = r.f;
         df = r.df;
         ++counter;

@@ -286,8 +286,9 @@ mi_status mi_edm_debug_read(mi_edm* e, float* v, float* s, float* w, float* t0, 
 mi_status mi_edm_last_timings(mi_edm* e, float ms[4]);
 
 /* Test hook: evaluate the device math routines of the pipeline on arrays
- * (op: 0 exp, 1 log, 2 pow(a,b), 3 erfinv) so that tests can compare them with
- * oracle/edm_oracle.c bit for bit.  Device pointers; b_dev may be NULL. */
+ * (op: 0 exp, 1 log, 2 pow(a,b), 3 erfinv; 4: a / b[0] the way the kernels divide
+ * by a wave-uniform divisor, 5: a / b[0] by IEEE division) so that tests can compare
+ * them with oracle/edm_oracle.c bit for bit.  Device pointers; b_dev may be NULL. */
 mi_status mi_edm_math_probe(mi_ctx* ctx, int math_mode, int op, const float* a_dev, const float* b_dev,
                             float* out_dev, size_t n);
 

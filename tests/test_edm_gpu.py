@@ -37,6 +37,55 @@ def _probe(ctx, mode, op, a, b=None):
     return out.cpu().numpy()
 
 
+def test_uniform_divisor_quotient_is_the_ieee_quotient(mi_ctx, evolve_form):
+    """div_by (csrc/mi_edm_math.hpp): the five-operation quotient by a wave-uniform divisor against IEEE division, bit for
+    bit, over random bit patterns (every exponent, both signs, zeros, subnormals, infinities, NaNs) and numerators spread
+    over the exponents the shortcut accepts and a little beyond, for the divisors of the reference's model (1 - beta,
+    beta - 1, vth - I) and awkward ones (significand all ones, powers of two, the edges of the accepted range and beyond)."""
+    if evolve_form != "auto":
+        pytest.skip("no evolve kernel involved")
+    rng = np.random.default_rng(7)
+    n = 1 << 24
+    bits = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    mant = rng.integers(0, 1 << 23, n, dtype=np.uint32)
+    expo = rng.integers(127 - 104, 127 + 104, n, dtype=np.uint32)
+    spread = ((rng.integers(0, 2, n, dtype=np.uint32) << 31) | (expo << 23) | mant).view(np.float32)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.1754944e-38, 3.4028235e38, 2.0 ** -100, 2.0 ** 100,
+                        np.nextafter(np.float32(2.0 ** -100), np.float32(0)), np.nextafter(np.float32(2.0 ** 100), np.float32(np.inf))], np.float32)
+    a = np.concatenate([bits, spread, special])
+    beta = np.float32(13.0589)
+    divisors = [np.float32(1.0) - beta, beta - np.float32(1.0), np.float32(1.0) - np.float32(0.9), np.float32(0.1), np.float32(3.0),
+                np.float32(-7.0), np.float32(1.9999999), np.float32(1.0000001), np.float32(0.5), np.float32(2.0 ** -20), np.float32(2.0 ** 20),
+                np.float32(2.0 ** -21), np.float32(2.0 ** 21), np.float32(1e-30), np.float32(np.inf), np.float32(0.0)]
+    for c in divisors:
+        cb = np.concatenate([np.full(4, c, np.float32), a[4:]])
+        got = _probe(mi_ctx, 0, 4, a, cb)
+        want = _probe(mi_ctx, 0, 5, a, cb)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (c, a[~same][:5], got[~same][:5], want[~same][:5])
+        with np.errstate(all="ignore"):
+            host = (a / c).astype(np.float32)
+        ok = (want.view(np.uint32) == host.view(np.uint32)) | (np.isnan(want) & np.isnan(host))
+        assert ok.all(), ("device IEEE division differs from numpy", c)
+
+
+def test_uniform_division_path_changes_nothing(mi_ctx, monkeypatch):
+    """N = 512 (the reference's Driver.cu grid) takes the exact quotient by uniform divisors in the wave-per-realisation
+    kernel; MI_EDM_NO_UNIFORM_DIV switches it off.  Every event array must be the same either way."""
+    monkeypatch.setenv("MI_EDM_WAVES_PER_REALISATION", "1")
+    taps = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("MI_EDM_NO_UNIFORM_DIV", "1")
+        else:
+            monkeypatch.delenv("MI_EDM_NO_UNIFORM_DIV", raising=False)
+        edm, f, partial, dbg = _run(mi_ctx, n_grid=512, n_real=3500)       # enough realisations for the path to be chosen
+        taps.append((f, partial, dbg))
+    for k in ("t0", "i0", "t1", "i1", "accept", "restricted"):
+        assert np.array_equal(taps[0][2][k], taps[1][2][k], equal_nan=True), k
+    assert np.array_equal(taps[0][0], taps[1][0]) and np.array_equal(taps[0][1], taps[1][1])
+
+
 def test_device_math_bit_identical_to_oracle(mi_ctx, evolve_form):
     if evolve_form != "auto":
         pytest.skip("no evolve kernel involved")
@@ -282,6 +331,23 @@ def test_reference_mean_at_the_driver_size(mi_ctx, n_grid):
     _, ft, pt, _ = _run(mi_ctx, n_grid=n_grid, n_real=R, mean_quirk=0)
     assert np.array_equal(ft, fref(R, False)) and np.array_equal(pt[:3], R * x) and np.all(pt[4:] == 0)
     assert np.allclose(f - ft, x / R, rtol=0, atol=2e-7) and np.all(np.abs(f - ft) > 5e-4)
+
+
+def test_driver_grid_many_realisations_match_the_oracle(mi_ctx):
+    """The reference's Driver.cu grid (N = 512) with enough realisations for the wave-per-realisation kernel to take the
+    exact quotient by uniform divisors (csrc/mi_edm_math.hpp div_by): every row must equal row 0, and row 0 the oracle's
+    realisation -- the oracle divides with `/`."""
+    R = 20_000
+    d, x, fref = _one_realisation_reference(512, Z_DRIVER)
+    edm, f, partial, dbg = _run(mi_ctx, n_grid=512, n_real=R)
+    for k in ("t0", "i0", "t1", "i1"):
+        a = dbg[k].reshape(3, R)
+        assert np.all(a == a[:, :1]), k
+        assert np.array_equal(a[:, 0], d[k].reshape(3, 1)[:, 0]), k
+    assert np.all(dbg["accept"] == 1) and partial[3] == R
+    assert np.array_equal(dbg["restricted"].reshape(3, R)[:, 0], d["restricted"])
+    assert np.array_equal(f, fref(R, True))
+    edm.close()
 
 
 @pytest.mark.timeout(600)
