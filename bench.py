@@ -363,6 +363,15 @@ def main():
                 "realisations_per_s": 125_000 / (tmg["total_ms"] * 1e-3),
                 "note": "compute-bound in Evolve (fp32 exp/log/div), not a bandwidth roofline case"}
             edm.close()
+        # the same share on the grid of the reference's Driver.cu (N = 512, configs[4])
+        edm = mi.EventDrivenMap(ctx, [13.0589], 125_000, n_grid=512, math_mode=mi.MATH_EXACT)
+        edm.ComputeF(zd)
+        edm.ComputeF(zd)
+        tmg = edm.last_timings()
+        extra["compute_f_125k_real_512pts_exact"] = {
+            "ms": tmg["total_ms"], "evolve_ms": tmg["evolve_ms"], "restrict_mean_ms": tmg["restrict_mean_ms"],
+            "realisations_per_s": 125_000 / (tmg["total_ms"] * 1e-3)}
+        edm.close()
         # the same call with the opt-in shortcut for sigma = 0 (config 4 has sigma = 0: its realisations are R copies of
         # one computation); reported beside the full evolution above, never instead of it
         edm = mi.EventDrivenMap(ctx, [13.0589], 125_000, n_grid=1024, dedup_identical=1)
