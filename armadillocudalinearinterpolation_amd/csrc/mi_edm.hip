@@ -186,12 +186,24 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
     const float two_T = 2.0f * M.T;
 
     for (unsigned r = blockIdx.x * (kEvolveBlock / 64) + wave; r < M.R; r += waves_per_grid) {
+        // Slices whose every neuron starts with v AND s NaN (the stretch that the lift profile poisons through 0 * inf,
+        // LiftKernel :505-542 -- 243 contiguous neurons at the reference's parameters): NaN stays NaN under every update
+        // of the event loop (v e1 + ..., (...) * 0 at a reset, s e3 + beta w), such a neuron never fires (will_fire is false
+        // for a NaN s) and is never the firing neuron, so the state pass skips these slices and only their standing
+        // contribution to the arg-min -- the time kNever at the lane's lowest such index -- is kept (nan_i).
+        unsigned skip = 0;            // bit k: slice k is all-NaN (wave-uniform)
+        unsigned nan_i = ~0u;         // this lane's lowest neuron index inside the skipped slices
         for (unsigned k = 0; k < npl; ++k) {
             const unsigned i = k * 64u + lane;
             const bool act = i < M.N;
-            V[i] = act ? v0[i] : 0.0f;
-            S[i] = act ? s0[i] : 0.0f;
+            const float vi = act ? v0[i] : 0.0f, si = act ? s0[i] : 0.0f;
+            V[i] = vi;
+            S[i] = si;
             if constexpr (HETERO) B[i] = edm::beta_of<MATH>(M.beta_mean, M.beta_sigma, M.seed, M.N, (uint64_t)r + M.real_offset, act ? i : 0u);
+            if (__all(!act || (vi != vi && si != si)) && __any(act)) {
+                skip |= 1u << k;
+                if (act && nan_i == ~0u) nan_i = i;
+            }
         }
         // per-bump event slots ([D2]: start at time 0 / index 0); wave-uniform values
         float lt[NS], ct[NS];
@@ -215,6 +227,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
         unsigned base_i = 0;
         unsigned pend = 0;
         for (unsigned k = 0; k < npl; ++k) {
+            if ((skip >> k) & 1u) continue;
             const unsigned i = k * 64u + lane;
             if (i < M.N) {
                 const float bk = HETERO ? B[i] : M.beta_mean;
@@ -222,6 +235,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 else if (base_t == INFINITY) { base_t = edm::kNever; base_i = i; }
             }
         }
+        if (nan_i != ~0u && (base_t == INFINITY || nan_i < base_i)) { base_t = edm::kNever; base_i = nan_i; }
         unsigned events = 0;
 #if MI_EVOLVE_TIMING
         unsigned long long tacc[4] = {0, 0, 0, 0};
@@ -247,11 +261,17 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             wave_argmin(best, idx);
             const float dt = best;
             // analytic state advance (EventDrivenMap.cu:612-617), fused with the firing test for the NEXT event
-            const float e1 = edm::expf_<MATH>(-dt);
-            float e2u = 0.0f, e3u = 0.0f;
+            float e1, e2u = 0.0f, e3u = 0.0f;
             if constexpr (!HETERO) {
-                e2u = edm::expf_<MATH>((1.0f - M.beta_mean) * dt);
-                e3u = edm::expf_<MATH>(-M.beta_mean * dt);
+                // the three wave-uniform exponentials of the advance in ONE pass of the software exp: lanes 0, 1, 2 take the
+                // three arguments, the results come back through v_readlane (same routine, same inputs: same bits)
+                const float arg = (lane == 1u) ? (1.0f - M.beta_mean) * dt : (lane == 2u) ? -M.beta_mean * dt : -dt;
+                const float ex = edm::expf_<MATH>(arg);
+                e1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ex), 0));
+                e2u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ex), 1));
+                e3u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ex), 2));
+            } else {
+                e1 = edm::expf_<MATH>(-dt);
             }
             base_t = INFINITY;
             base_i = 0;
@@ -261,6 +281,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             MI_EV_STAMP(1)
 #pragma unroll MI_EVOLVE_UNROLL
             for (unsigned k = 0; k < npl; ++k) {
+                if ((skip >> k) & 1u) continue;          // all-NaN slice: nothing to advance
                 const unsigned i = k * 64u + lane;
                 const float bk = HETERO ? B[i] : M.beta_mean;
                 const float e2 = HETERO ? edm::expf_<MATH>((1.0f - bk) * dt) : e2u;
@@ -285,6 +306,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                     else if (base_t == INFINITY) { base_t = edm::kNever; base_i = i; }
                 }
             }
+            if (nan_i != ~0u && (base_t == INFINITY || nan_i < base_i)) { base_t = edm::kNever; base_i = nan_i; }
             MI_EV_STAMP(2)
             now = now + dt;
             // which bump does the event belong to ([D3]: the reference's increment rule, :625-629)
