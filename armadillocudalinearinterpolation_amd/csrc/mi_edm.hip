@@ -556,6 +556,15 @@ __global__ void math_probe_kernel(int op, const float* a, const float* b, float*
         case 2: r = edm::powf_<MATH>(a[i], b[i]); break;
         case 4: r = edm::div_by<MATH, true>(a[i], b[0]); break;    // quotient by a wave-uniform divisor (b[0])
         case 5: r = a[i] / b[0]; break;                           // the IEEE expansion, for comparison
+        case 6: case 7: case 8: case 9: case 10: case 11: {       // will_fire(v0 = a, s0 = b): exact path (even op) / with the
+            edm::Model M = {};                                    // hardware pre-decision (odd op); beta by op pair
+            M.vth = 1.0f;
+            M.I = 0.9f;
+            const float beta = op < 8 ? 13.0589f : op < 10 ? 1.5f : 0.7f;
+            r = (op & 1) ? (edm::will_fire<MATH, false, true>(M, a[i], b[i], beta) ? 1.0f : 0.0f)
+                         : (edm::will_fire<MATH, false, false>(M, a[i], b[i], beta) ? 1.0f : 0.0f);
+            break;
+        }
         default: r = edm::erfinvf_<MATH>(a[i]); break;
     }
     out[i] = r;
@@ -1012,7 +1021,8 @@ mi_status mi_edm_last_timings(mi_edm* e, float ms[4])
 }
 
 // test hook: run the device math routines on arrays (op: 0 exp, 1 log, 2 pow, 3 erfinv, 4 a / b[0] as the kernels
-// divide by a wave-uniform divisor, 5 a / b[0] as IEEE division)
+// divide by a wave-uniform divisor, 5 a / b[0] as IEEE division, 6-11 the firing test will_fire(a, b) without / with its
+// hardware pre-decision for beta = 13.0589, 1.5, 0.7)
 mi_status mi_edm_math_probe(mi_ctx* ctx, int math_mode, int op, const float* a_dev, const float* b_dev,
                             float* out_dev, size_t n)
 {

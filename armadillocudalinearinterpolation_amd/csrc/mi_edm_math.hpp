@@ -11,6 +11,9 @@
 #include <cstdint>
 
 #define MI_HD __host__ __device__ __forceinline__
+#ifndef MI_EDM_FIRE_FILTER
+#define MI_EDM_FIRE_FILTER 1   // will_fire: settle the clear cases with the hardware transcendentals (0: always the exact path)
+#endif
 
 namespace edm {
 
@@ -223,7 +226,7 @@ MI_HD FdF fun_dfun_e(const Model& M, float e1, float e2, float v, float s, float
 // At t = 0 both exponentials are exactly 1 (expf_(+-0) == 1), so the first evaluation needs no exp.
 constexpr float kNever = 100.0f;
 
-template <int MATH, bool UNI = false>
+template <int MATH, bool UNI = false, bool FILTER = (MI_EDM_FIRE_FILTER != 0)>
 MI_HD bool will_fire(const Model& M, float v0, float s0, float beta)
 {
     const float gap = M.vth - M.I;
@@ -232,6 +235,35 @@ MI_HD bool will_fire(const Model& M, float v0, float s0, float beta)
     // does a NaN (the poisoned stretch of the lift profile: 3.8 of 16 slices per event at N = 1024); the inhibitory
     // surround puts most of the ring in the first case, 64 contiguous neurons per wave step.
     if (gap > 0.0f && gap <= 1.0f && !(s0 >= 0.0f)) return false;   // s0 < 0, or NaN: NaN / gap is NaN and fails `ratio >= 0` below
+#if defined(__HIP_DEVICE_COMPILE__)
+    // EXACT mode, s0 >= 0: the test v0 > thr costs a software log, a software exp and three IEEE divisions (about 86
+    // instructions on 3.2 slices per event) and is almost never close.  Evaluate thr first with the hardware transcendentals
+    // (v_rcp_f32, v_log_f32, v_exp_f32: 1 ulp each) and settle every case that is clear of it by 1e-4 of the summed
+    // magnitudes of its terms; close calls, NaN, zero and extreme arguments take the exact path below, so the decision
+    // is the exact path's whenever the two evaluations could disagree.  Error budget: the two values of
+    // pw = ratio^(1/beta) differ relatively by at most ln 2 |log2(ratio)/beta| 2^-22 (argument error of either
+    // exponential) + a few ulp, i.e. < 3.5e-6 under the guard |log2(ratio)/beta| <= 16; thr is affine in pw and ratio
+    // with coefficients bounded by the magnitudes summed in `mag`, so |thr_hw - thr_exact| < 4e-6 mag: a factor 25
+    // inside the margin.  tests/test_edm_gpu.py compares the decisions of both forms on dense samples around the
+    // threshold (math probe ops 6, 7) and every stage tap of ComputeF with the oracle.
+    if constexpr (MATH == 0 && FILTER) {
+        if (gap > 0.0f && gap <= 1.0f) {                        // (s0 >= 0 here)
+            const float rf = s0 * __builtin_amdgcn_rcpf(gap);
+            const float ex = __builtin_amdgcn_logf(rf) * __builtin_amdgcn_rcpf(beta);       // log2(ratio) / beta
+            if (rf >= 0x1.0p-40f && rf <= 0x1.0p+40f && fabsf(ex) <= 16.0f) {
+                const float pwf = __builtin_amdgcn_exp2f(ex);
+                const float c = gap * __builtin_amdgcn_rcpf(beta - 1.0f);
+                const float thrf = (M.vth * pwf + M.I * (1.0f - pwf)) - c * (rf - pwf);
+                const float mag = (fabsf(M.vth) * pwf + fabsf(M.I) * (1.0f + pwf)) + fabsf(c) * (rf + pwf);
+                const float margin = 1.0e-4f * mag;
+                if (mag < INFINITY) {
+                    if (v0 > thrf + margin) return true;
+                    if (v0 < thrf - margin) return false;
+                }
+            }
+        }
+    }
+#endif
     const float ratio = div_by<MATH, UNI>(s0, gap);   // (gap is always uniform; UNI only says whether the kernel opted in)
     if (!(ratio >= 0.0f)) return false;
     const float pw = powf_<MATH>(ratio, div_<MATH>(1.0f, beta));

@@ -287,7 +287,9 @@ mi_status mi_edm_last_timings(mi_edm* e, float ms[4]);
 
 /* Test hook: evaluate the device math routines of the pipeline on arrays
  * (op: 0 exp, 1 log, 2 pow(a,b), 3 erfinv; 4: a / b[0] the way the kernels divide
- * by a wave-uniform divisor, 5: a / b[0] by IEEE division) so that tests can compare
+ * by a wave-uniform divisor, 5: a / b[0] by IEEE division; 6..11: the firing test
+ * will_fire(v0 = a, s0 = b) -> 0/1 on its exact path (even op) and with its hardware
+ * pre-decision (odd op) for beta = 13.0589, 1.5, 0.7) so that tests can compare
  * them with oracle/edm_oracle.c bit for bit.  Device pointers; b_dev may be NULL. */
 mi_status mi_edm_math_probe(mi_ctx* ctx, int math_mode, int op, const float* a_dev, const float* b_dev,
                             float* out_dev, size_t n);

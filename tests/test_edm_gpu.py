@@ -69,6 +69,46 @@ def test_uniform_divisor_quotient_is_the_ieee_quotient(mi_ctx, evolve_form):
         assert ok.all(), ("device IEEE division differs from numpy", c)
 
 
+def test_firing_test_pre_decision_never_changes_the_decision(mi_ctx, evolve_form):
+    """will_fire (csrc/mi_edm_math.hpp) settles cases that are clear of the threshold with the hardware transcendentals and
+    leaves the rest to the exact path: both forms must give the same decision everywhere -- checked on synaptic values over
+    20 decades with the membrane value placed AT the exact threshold, within a few ulp of it, within the margin, just
+    outside it and far away, for three values of beta."""
+    if evolve_form != "auto":
+        pytest.skip("no evolve kernel involved")
+    rng = np.random.default_rng(11)
+    n = 1 << 21
+    gap = np.float32(1.0) - np.float32(0.9)
+    s0 = (10.0 ** rng.uniform(-12, 8, n)).astype(np.float32)
+    s0[: n // 8] = (gap * (10.0 ** rng.uniform(-2, 2, n // 8))).astype(np.float32)        # ratio around 1
+    for op_exact, beta in ((6, 13.0589), (8, 1.5), (10, 0.7)):
+        # locate the exact threshold in v0 for every s0 by bisection on the exact path's decision (monotone in v0)
+        lo = np.full(n, -1e6, np.float32)
+        hi = np.full(n, 1e6, np.float32)
+        for _ in range(60):
+            mid = ((lo.astype(np.float64) + hi.astype(np.float64)) * 0.5).astype(np.float32)
+            fire = _probe(mi_ctx, 0, op_exact, mid, s0) > 0.5
+            hi = np.where(fire, mid, hi)
+            lo = np.where(fire, lo, mid)
+        thr = hi                                                                            # smallest v0 found that fires
+        scale = np.maximum(np.abs(thr), np.float32(1e-3))
+        cands = [thr, lo, np.nextafter(thr, np.float32(np.inf)), np.nextafter(lo, np.float32(-np.inf))]
+        for rel in (1e-7, 1e-6, 1e-5, 5e-5, 9e-5, 1.1e-4, 2e-4, 1e-3, 1e-2, 1.0):
+            cands += [(thr + np.float32(rel) * scale).astype(np.float32), (thr - np.float32(rel) * scale).astype(np.float32)]
+        cands += [rng.standard_normal(n).astype(np.float32), np.full(n, np.nan, np.float32), np.full(n, np.inf, np.float32)]
+        for v0 in cands:
+            a = _probe(mi_ctx, 0, op_exact, v0, s0)
+            b = _probe(mi_ctx, 0, op_exact + 1, v0, s0)
+            assert np.array_equal(a, b), (beta, v0[a != b][:5], s0[a != b][:5])
+    # special synaptic values
+    sv = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, -1.0, 1e-45, 3e38, 1e-30, 1e30], np.float32)
+    vv = np.array([0.95, 0.5, 0.2, 1.0, 1.5, 0.99, 0.9, 0.91, 1.01, -3.0], np.float32)
+    for op_exact in (6, 8, 10):
+        for shift in range(len(vv)):
+            v0 = np.roll(vv, shift)
+            assert np.array_equal(_probe(mi_ctx, 0, op_exact, v0, sv), _probe(mi_ctx, 0, op_exact + 1, v0, sv))
+
+
 def test_uniform_division_path_changes_nothing(mi_ctx, monkeypatch):
     """N = 512 (the reference's Driver.cu grid) takes the exact quotient by uniform divisors in the wave-per-realisation
     kernel; MI_EDM_NO_UNIFORM_DIV switches it off.  Every event array must be the same either way."""
