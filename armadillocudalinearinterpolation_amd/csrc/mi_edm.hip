@@ -289,12 +289,12 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 const float so = S[i];
                 float vv = V[i] * e1;
                 vv = vv + (M.I * (1.0f - e1) + edm::div_by<MATH, UDIV && !HETERO>(so * e1, 1.0f - bk) * (e2 - 1.0f));
-                // reset of the neuron that fired (:615 multiplies every v by (tid != index)): x*1 == x, so only
-                // the slice that holds idx needs the multiply
-                if (k == (idx >> 6)) vv = vv * ((i != idx) ? 1.0f : 0.0f);
+                // reset of the neuron that fired (:615 multiplies every v by (tid != index)): x * 1 == x, so only that
+                // neuron needs the multiply (by 0: NaN stays NaN, a finite value becomes a signed zero)
+                vv = (i == idx) ? vv * 0.0f : vv;
                 float sn = so * e3;
-                const unsigned dist = (unsigned)abs((int)i - (int)idx);
-                sn = sn + bk * w_lds[dist & (kMaxGrid - 1)];
+                const unsigned dist = (unsigned)abs((int)i - (int)idx);   // < kMaxGrid: i < slots <= kMaxGrid, idx < N
+                sn = sn + bk * w_lds[dist];
                 V[i] = vv;
                 S[i] = sn;
 #if MI_EVOLVE_TIMING
