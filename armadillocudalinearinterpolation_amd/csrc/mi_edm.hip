@@ -259,7 +259,10 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             }
             MI_EV_STAMP(0)
             wave_argmin(best, idx);
-            const float dt = best;
+            // the winner is the same in every lane: in scalar registers the event bookkeeping below (nearest bump,
+            // crossed mask) runs on the scalar unit
+            idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+            const float dt = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, best)));
             // analytic state advance (EventDrivenMap.cu:612-617), fused with the firing test for the NEXT event
             float e1, e2u = 0.0f, e3u = 0.0f;
             if constexpr (!HETERO) {
