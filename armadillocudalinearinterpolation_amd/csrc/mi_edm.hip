@@ -193,6 +193,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
         // contribution to the arg-min -- the time kNever at the lane's lowest such index -- is kept (nan_i).
         unsigned skip = 0;            // bit k: slice k is all-NaN (wave-uniform)
         unsigned nan_i = ~0u;         // this lane's lowest neuron index inside the skipped slices
+        unsigned valid = 0;           // bit k: neuron k*64+lane exists and its slice is advanced
         for (unsigned k = 0; k < npl; ++k) {
             const unsigned i = k * 64u + lane;
             const bool act = i < M.N;
@@ -203,6 +204,8 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             if (__all(!act || (vi != vi && si != si)) && __any(act)) {
                 skip |= 1u << k;
                 if (act && nan_i == ~0u) nan_i = i;
+            } else if (act) {
+                valid |= 1u << k;
             }
         }
         // per-bump event slots ([D2]: start at time 0 / index 0); wave-uniform values
@@ -232,10 +235,18 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             if (i < M.N) {
                 const float bk = HETERO ? B[i] : M.beta_mean;
                 if (edm::will_fire<MATH, UDIV && !HETERO>(M, V[i], S[i], bk)) pend |= (1u << k);
-                else if (base_t == INFINITY) { base_t = edm::kNever; base_i = i; }
             }
         }
-        if (nan_i != ~0u && (base_t == INFINITY || nan_i < base_i)) { base_t = edm::kNever; base_i = nan_i; }
+        // the lane's lowest neuron that will not fire, from the masks (no per-slice tracking); the skipped slices' standing
+        // candidate folded in
+        auto lowest_quiet = [&]() {
+            const unsigned quiet = ~pend & valid;
+            base_t = INFINITY;
+            base_i = 0;
+            if (quiet != 0u) { base_t = edm::kNever; base_i = (unsigned)__builtin_ctz(quiet) * 64u + lane; }
+            if (nan_i != ~0u && (base_t == INFINITY || nan_i < base_i)) { base_t = edm::kNever; base_i = nan_i; }
+        };
+        lowest_quiet();
         unsigned events = 0;
 #if MI_EVOLVE_TIMING
         unsigned long long tacc[4] = {0, 0, 0, 0};
@@ -276,8 +287,6 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             } else {
                 e1 = edm::expf_<MATH>(-dt);
             }
-            base_t = INFINITY;
-            base_i = 0;
 #if MI_EVOLVE_TIMING
             asm volatile("" : "+v"(e2u), "+v"(e3u));
 #endif
@@ -306,10 +315,9 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
 #endif
                 if (i < M.N) {
                     if (edm::will_fire<MATH, UDIV && !HETERO>(M, vv, sn, bk)) pend |= (1u << k);
-                    else if (base_t == INFINITY) { base_t = edm::kNever; base_i = i; }
                 }
             }
-            if (nan_i != ~0u && (base_t == INFINITY || nan_i < base_i)) { base_t = edm::kNever; base_i = nan_i; }
+            lowest_quiet();
             MI_EV_STAMP(2)
             now = now + dt;
             // which bump does the event belong to ([D3]: the reference's increment rule, :625-629)
