@@ -313,10 +313,9 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 if (__any(i < M.N && !(sn < 0.0f))) ++nslow;       // slices that reach will_fire's division
                 if (__any(i < M.N && sn >= 0.0f)) ++npow;          // ... and its log/exp
 #endif
-                if (i < M.N) {
-                    if (edm::will_fire<MATH, UDIV && !HETERO>(M, vv, sn, bk)) pend |= (1u << k);
-                }
+                if (edm::will_fire<MATH, UDIV && !HETERO>(M, vv, sn, bk)) pend |= (1u << k);   // (padding lanes: masked below)
             }
+            pend &= valid;
             lowest_quiet();
             MI_EV_STAMP(2)
             now = now + dt;
