@@ -398,12 +398,14 @@ __global__ __launch_bounds__(64 * W) void evolve_wg_kernel(edm::Model M, SpikeSe
     __syncthreads();
 
     for (unsigned r = blockIdx.x; r < M.R; r += gridDim.x) {
+        unsigned valid = 0;           // bit k: neuron (k*W + wave)*64 + lane exists
         for (unsigned k = 0; k < npl; ++k) {
             const unsigned i = (k * W + wave) * 64u + lane;
             const bool act = i < M.N;
             V[i] = act ? v0[i] : 0.0f;
             S[i] = act ? s0[i] : 0.0f;
             if constexpr (HETERO) B[i] = edm::beta_of<MATH>(M.beta_mean, M.beta_sigma, M.seed, M.N, (uint64_t)r + M.real_offset, act ? i : 0u);
+            valid |= act ? (1u << k) : 0u;
         }
         float lt[NS], ct[NS];
         unsigned li[NS], ci[NS];
@@ -424,9 +426,16 @@ __global__ __launch_bounds__(64 * W) void evolve_wg_kernel(edm::Model M, SpikeSe
             if (i < M.N) {
                 const float bk = HETERO ? B[i] : M.beta_mean;
                 if (edm::will_fire<MATH>(M, V[i], S[i], bk)) pend |= (1u << k);
-                else if (base_t == INFINITY) { base_t = edm::kNever; base_i = i; }
             }
         }
+        // the lane's lowest neuron that will not fire, from the masks (as in evolve_kernel)
+        auto lowest_quiet = [&]() {
+            const unsigned quiet = ~pend & valid;
+            base_t = INFINITY;
+            base_i = 0;
+            if (quiet != 0u) { base_t = edm::kNever; base_i = ((unsigned)__builtin_ctz(quiet) * W + wave) * 64u + lane; }
+        };
+        lowest_quiet();
         unsigned events = 0;
         while (crossed < full && now < two_T && events < M.max_events) {
             ++events;
@@ -461,14 +470,16 @@ __global__ __launch_bounds__(64 * W) void evolve_wg_kernel(edm::Model M, SpikeSe
                 idx = ib;
             }
             const float dt = best;
-            const float e1 = edm::expf_<MATH>(-dt);
-            float e2u = 0.0f, e3u = 0.0f;
-            if constexpr (!HETERO) {
-                e2u = edm::expf_<MATH>((1.0f - M.beta_mean) * dt);
-                e3u = edm::expf_<MATH>(-M.beta_mean * dt);
+            float e1, e2u = 0.0f, e3u = 0.0f;
+            if constexpr (!HETERO) {         // the three uniform exponentials in one pass of the software exp (lanes 0, 1, 2)
+                const float arg = (lane == 1u) ? (1.0f - M.beta_mean) * dt : (lane == 2u) ? -M.beta_mean * dt : -dt;
+                const float ex = edm::expf_<MATH>(arg);
+                e1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ex), 0));
+                e2u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ex), 1));
+                e3u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ex), 2));
+            } else {
+                e1 = edm::expf_<MATH>(-dt);
             }
-            base_t = INFINITY;
-            base_i = 0;
             for (unsigned k = 0; k < npl; ++k) {
                 const unsigned sl = k * W + wave;
                 const unsigned i = sl * 64u + lane;
@@ -478,17 +489,16 @@ __global__ __launch_bounds__(64 * W) void evolve_wg_kernel(edm::Model M, SpikeSe
                 const float so = S[i];
                 float vv = V[i] * e1;
                 vv = vv + (M.I * (1.0f - e1) + edm::div_<MATH>(so * e1, 1.0f - bk) * (e2 - 1.0f));
-                if (sl == (idx >> 6)) vv = vv * ((i != idx) ? 1.0f : 0.0f);
+                vv = (i == idx) ? vv * 0.0f : vv;             // reset of the neuron that fired
                 float sn = so * e3;
-                const unsigned dist = (unsigned)abs((int)i - (int)idx);
-                sn = sn + bk * w_lds[dist & (kMaxGrid - 1)];
+                const unsigned dist = (unsigned)abs((int)i - (int)idx);   // < kMaxGrid
+                sn = sn + bk * w_lds[dist];
                 V[i] = vv;
                 S[i] = sn;
-                if (i < M.N) {
-                    if (edm::will_fire<MATH>(M, vv, sn, bk)) pend |= (1u << k);
-                    else if (base_t == INFINITY) { base_t = edm::kNever; base_i = i; }
-                }
+                if (edm::will_fire<MATH>(M, vv, sn, bk)) pend |= (1u << k);   // (padding lanes: masked below)
             }
+            pend &= valid;
+            lowest_quiet();
             now = now + dt;
             unsigned mi = 0;
 #pragma unroll
