@@ -37,7 +37,7 @@ constexpr int kEvolveBlock = 256;   // 4 waves = 4 realisations per workgroup
 // max_events events (the realisation is then simply not accepted); the oracle applies the same rule.
 constexpr unsigned kMaxEventsLimit = 1u << 24;
 #ifndef MI_EVOLVE_UNROLL
-#define MI_EVOLVE_UNROLL 1           // state-pass unroll (measured: see DESIGN.md)
+#define MI_EVOLVE_UNROLL 1           // state-pass unroll of the homogeneous model (measured: see DESIGN.md); per-neuron beta: 4
 #endif
 
 struct SpikeSeeds {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             asm volatile("" : "+v"(e2u), "+v"(e3u));
 #endif
             MI_EV_STAMP(1)
-#pragma unroll MI_EVOLVE_UNROLL
+#pragma unroll (HETERO ? 4 : MI_EVOLVE_UNROLL)
             for (unsigned k = 0; k < npl; ++k) {
                 if ((skip >> k) & 1u) continue;          // all-NaN slice: nothing to advance
                 const unsigned i = k * 64u + lane;
