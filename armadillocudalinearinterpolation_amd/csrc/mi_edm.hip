@@ -174,7 +174,11 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
     const unsigned npl = (M.N + 63u) / 64u;
     const unsigned slots = npl * 64u;
     float* w_lds = lds;
-    for (unsigned i = threadIdx.x; i < (unsigned)kMaxGrid; i += kEvolveBlock) w_lds[i] = (i < M.N) ? w[i] : 0.0f;
+    // homogeneous model: the table holds RN(beta * w[d]), the product every event would otherwise form again
+    for (unsigned i = threadIdx.x; i < (unsigned)kMaxGrid; i += kEvolveBlock) {
+        const float wi = (i < M.N) ? w[i] : 0.0f;
+        w_lds[i] = HETERO ? wi : M.beta_mean * wi;
+    }
     __syncthreads();
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     constexpr unsigned kArrays = HETERO ? 3u : 2u;
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 vv = (i == idx) ? vv * 0.0f : vv;
                 float sn = so * e3;
                 const unsigned dist = (unsigned)abs((int)i - (int)idx);   // < kMaxGrid: i < slots <= kMaxGrid, idx < N
-                sn = sn + bk * w_lds[dist];
+                sn = sn + (HETERO ? bk * w_lds[dist] : w_lds[dist]);
                 V[i] = vv;
                 S[i] = sn;
 #if MI_EVOLVE_TIMING
@@ -387,7 +391,10 @@ __global__ __launch_bounds__(64 * W) void evolve_wg_kernel(edm::Model M, SpikeSe
     const unsigned npl = (M.N + kBlockT - 1u) / kBlockT;      // slices per wave
     const unsigned slots = npl * kBlockT;
     float* w_lds = lds;
-    for (unsigned i = threadIdx.x; i < (unsigned)kMaxGrid; i += kBlockT) w_lds[i] = (i < M.N) ? w[i] : 0.0f;
+    for (unsigned i = threadIdx.x; i < (unsigned)kMaxGrid; i += kBlockT) {   // homogeneous model: RN(beta * w[d]), as in evolve_kernel
+        const float wi = (i < M.N) ? w[i] : 0.0f;
+        w_lds[i] = HETERO ? wi : M.beta_mean * wi;
+    }
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float* V = lds + kMaxGrid;
     float* S = V + slots;
@@ -492,7 +499,7 @@ __global__ __launch_bounds__(64 * W) void evolve_wg_kernel(edm::Model M, SpikeSe
                 vv = (i == idx) ? vv * 0.0f : vv;             // reset of the neuron that fired
                 float sn = so * e3;
                 const unsigned dist = (unsigned)abs((int)i - (int)idx);   // < kMaxGrid
-                sn = sn + bk * w_lds[dist];
+                sn = sn + (HETERO ? bk * w_lds[dist] : w_lds[dist]);
                 V[i] = vv;
                 S[i] = sn;
                 if (edm::will_fire<MATH>(M, vv, sn, bk)) pend |= (1u << k);   // (padding lanes: masked below)
