@@ -60,45 +60,46 @@ __global__ __launch_bounds__(kMaxGrid) void lift_kernel(edm::Model M, SpikeSeeds
     const float xc = x / c;
     float sv = 0.0f, ss = 0.0f;
     for (unsigned m = 1; m <= M.S; ++m) {
+        // every product, quotient and sum below is grouped as C groups the reference's expression (:522-534):
+        // left to right, `-b1*c*U` = ((-b1)*c)*U, `a1*beta*c/(..)` = ((a1*beta)*c)/(..)  (== oracle/edm_oracle.c)
         const float Um = sd.U[m];
         const float cu = c * Um;
         const float d = x - cu;
         const float pos = (d > 0.0f) ? 1.0f : 0.0f;
         const float neg = (d <= 0.0f) ? 1.0f : 0.0f;
-        float brA = 0.0f, brB = 0.0f, sa = 0.0f, sb = 0.0f;
         const float ebu = edm::expf_<MATH>(beta * Um);
-        const float dx = edm::expf_<MATH>(xc * omb) - edm::expf_<MATH>(Um * omb);
+        const float exo = edm::expf_<MATH>(xc * omb);
+        const float dxk[2] = {exo - edm::expf_<MATH>((cu / c) * omb),    // a1 term, :523: exp(((c*U)/c)*(1-beta))
+                              exo - edm::expf_<MATH>(Um * omb)};         // a2 term, :524: exp((U)*(1-beta))
         const float ebc = edm::expf_<MATH>(-(beta / c) * d);
+        float P[2], Q[2], R[2], B[2], sA[2], sB1[2], sB2[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const float sg = (k == 0) ? 1.0f : -1.0f;
             const float cb = c * b[k];
             const float abc = (a[k] * beta) * c;
-            const float Pk = abc / ((beta + cb) * (1.0f + cb));
-            const float Qk = abc / omb;
-            const float Rk = abc / ((cb - beta) * (1.0f - cb));
-            const float gk = 1.0f / (beta + cb) + 1.0f / (cb - beta);
             const float ep = (1.0f + cb) / c;
             const float em = (1.0f - cb) / c;
-            const float en = edm::expf_<MATH>(-(b[k] * cu));
-            const float epos = edm::expf_<MATH>(b[k] * cu);
-            const float tA = (Pk * edm::expf_<MATH>(cu * ep)) * en + ((Qk * ebu) * gk) * dx -
-                             (Rk * epos) * (edm::expf_<MATH>(x * em) - edm::expf_<MATH>(cu * em));
-            const float tB = (Pk * edm::expf_<MATH>(x * ep)) * en;
-            brA = brA + sg * tA;
-            brB = brB + sg * tB;
-            const float ta = ((beta * a[k]) * (c / (beta + cb))) * edm::expf_<MATH>(b[k] * d);
-            const float tb = (((2.0f * a[k]) / b[k]) * (beta / (1.0f - (beta * beta) / (((c * c) * b[k]) * b[k])))) * ebc -
-                             ((beta * a[k]) * (c / (cb - beta))) * edm::expf_<MATH>(b[k] * (cu - x));
-            sa = sa + sg * ta;
-            sb = sb + sg * tb;
+            const float Pk = abc / ((beta + cb) * (1.0f + cb));
+            const float en = edm::expf_<MATH>(-(cb * Um));               // exp(-b*c*U) = exp(((-b)*c)*U)
+            P[k] = (Pk * edm::expf_<MATH>(cu * ep)) * en;
+            Q[k] = (((abc / omb) * ebu) * (1.0f / (beta + cb) + 1.0f / (cb - beta))) * dxk[k];
+            R[k] = ((abc / ((cb - beta) * (1.0f - cb))) * edm::expf_<MATH>(cb * Um)) * (edm::expf_<MATH>(x * em) - edm::expf_<MATH>(cu * em));
+            B[k] = (Pk * edm::expf_<MATH>(x * ep)) * en;
+            // synaptic profile, :532-534
+            sA[k] = ((beta * a[k]) * (c / (beta + cb))) * edm::expf_<MATH>(b[k] * d);
+            sB1[k] = (((2.0f * a[k]) / b[k]) * (beta / (1.0f - (beta * beta) / (((c * c) * b[k]) * b[k])))) * ebc;
+            sB2[k] = ((beta * a[k]) * (c / (cb - beta))) * edm::expf_<MATH>(b[k] * (cu - x));
         }
+        // :522-527: P1 - P2 + Q1 - R1 - Q2 + R2, added left to right
+        const float brA = ((((P[0] - P[1]) + Q[0]) - R[0]) - Q[1]) + R[1];
+        const float brB = B[0] - B[1];
         const float dummyV = (pos * brA + neg * brB) * edm::expf_<MATH>(-xc);
-        sv = sv + (dummyV - pos * edm::expf_<MATH>(-d / c));
+        sv = sv + ((dummyV - pos * edm::expf_<MATH>(-d / c)) + neg * 0.0f);             // :530
+        // (cu - x) > 0  <=>  d < 0 ; (cu - x) <= 0  <=>  d >= 0
         const float e = cu - x;
         const float posS = (e > 0.0f) ? 1.0f : 0.0f;
         const float negS = (e <= 0.0f) ? 1.0f : 0.0f;
-        ss = ss + (posS * sa + negS * sb);
+        ss = ss + (posS * (sA[0] - sA[1]) + negS * (((sB1[0] - sB2[0]) - sB1[1]) + sB2[1]));
     }
     float vv = M.I + sv;
     vv = vv * ((vv < 1.0f) ? 1.0f : 0.0f);

@@ -210,8 +210,9 @@ void orc_edm_seed_indices(const orc_edm_params* P, const double* Z, uint16_t* in
  * in the reference, so an overflowing exponential in the unselected branch
  * still poisons the result with NaN (0*inf).  The profile does not depend on
  * the realisation, so it is computed once (v[N], s[N]).
- * [D7] exp(((c*U)/c)*(1-beta)) at :523 is evaluated as exp(U*(1-beta)), the
- * form the a2 term at :524 already uses. */
+ * The six terms of dummyV and the four of dummyS are added left to right, as
+ * written at :522-527 / :532-534; exp(((c*U)/c)*(1-beta)) of the a1 term (:523)
+ * and exp((U)*(1-beta)) of the a2 term (:524) are both kept as written. */
 void orc_edm_lift(const orc_edm_params* P, const float* U, float* v, float* s)
 {
     const uint32_t N = P->n_grid, S = P->n_spikes;
@@ -224,47 +225,45 @@ void orc_edm_lift(const orc_edm_params* P, const float* U, float* v, float* s)
         const float xc = x / c;
         float sv = 0.0f, ss = 0.0f;
         for (uint32_t m = 1; m <= S; ++m) {
+            /* every product, quotient and sum below is grouped as C groups the reference's expression (:522-534):
+             * left to right, `-b1*c*U` = ((-b1)*c)*U, `a1*beta*c/(..)` = ((a1*beta)*c)/(..) */
             const float Um = U[m];
             const float cu = c * Um;
             const float d = x - cu;
             const float pos = (d > 0.0f) ? 1.0f : 0.0f;
             const float neg = (d <= 0.0f) ? 1.0f : 0.0f;
-            float brA = 0.0f, brB = 0.0f, sa = 0.0f, sb = 0.0f;
             const float ebu = orc_edm_expf(beta * Um);
-            const float dx = orc_edm_expf(xc * omb) - orc_edm_expf(Um * omb);
+            const float exo = orc_edm_expf(xc * omb);
+            const float dxk[2] = {exo - orc_edm_expf((cu / c) * omb),    /* a1 term, :523: exp(((c*U)/c)*(1-beta)) */
+                                  exo - orc_edm_expf(Um * omb)};         /* a2 term, :524: exp((U)*(1-beta)) */
             const float ebc = orc_edm_expf(-(beta / c) * d);
+            float P[2], Q[2], R[2], B[2], sA[2], sB1[2], sB2[2];
             for (int k = 0; k < 2; ++k) {
-                const float sg = (k == 0) ? 1.0f : -1.0f;
                 const float cb = c * b[k];
                 const float abc = (a[k] * beta) * c;
-                const float Pk = abc / ((beta + cb) * (1.0f + cb));
-                const float Qk = abc / omb;
-                const float Rk = abc / ((cb - beta) * (1.0f - cb));
-                const float gk = 1.0f / (beta + cb) + 1.0f / (cb - beta);
                 const float ep = (1.0f + cb) / c;
                 const float em = (1.0f - cb) / c;
-                const float en = orc_edm_expf(-(b[k] * cu));
-                const float epos = orc_edm_expf(b[k] * cu);
-                const float tA = (Pk * orc_edm_expf(cu * ep)) * en
-                               + ((Qk * ebu) * gk) * dx
-                               - (Rk * epos) * (orc_edm_expf(x * em) - orc_edm_expf(cu * em));
-                const float tB = (Pk * orc_edm_expf(x * ep)) * en;
-                brA = brA + sg * tA;
-                brB = brB + sg * tB;
+                const float Pk = abc / ((beta + cb) * (1.0f + cb));
+                const float en = orc_edm_expf(-(cb * Um));               /* exp(-b*c*U) = exp(((-b)*c)*U) */
+                P[k] = (Pk * orc_edm_expf(cu * ep)) * en;
+                Q[k] = (((abc / omb) * ebu) * (1.0f / (beta + cb) + 1.0f / (cb - beta))) * dxk[k];
+                R[k] = ((abc / ((cb - beta) * (1.0f - cb))) * orc_edm_expf(cb * Um)) * (orc_edm_expf(x * em) - orc_edm_expf(cu * em));
+                B[k] = (Pk * orc_edm_expf(x * ep)) * en;
                 /* synaptic profile, :532-534 */
-                const float ta = ((beta * a[k]) * (c / (beta + cb))) * orc_edm_expf(b[k] * d);
-                const float tb = (((2.0f * a[k]) / b[k]) * (beta / (1.0f - (beta * beta) / (((c * c) * b[k]) * b[k])))) * ebc
-                               - ((beta * a[k]) * (c / (cb - beta))) * orc_edm_expf(b[k] * (cu - x));
-                sa = sa + sg * ta;
-                sb = sb + sg * tb;
+                sA[k] = ((beta * a[k]) * (c / (beta + cb))) * orc_edm_expf(b[k] * d);
+                sB1[k] = (((2.0f * a[k]) / b[k]) * (beta / (1.0f - (beta * beta) / (((c * c) * b[k]) * b[k])))) * ebc;
+                sB2[k] = ((beta * a[k]) * (c / (cb - beta))) * orc_edm_expf(b[k] * (cu - x));
             }
+            /* :522-527: P1 - P2 + Q1 - R1 - Q2 + R2, added left to right */
+            const float brA = ((((P[0] - P[1]) + Q[0]) - R[0]) - Q[1]) + R[1];
+            const float brB = B[0] - B[1];
             const float dummyV = (pos * brA + neg * brB) * orc_edm_expf(-xc);
-            sv = sv + (dummyV - pos * orc_edm_expf(-d / c));
+            sv = sv + ((dummyV - pos * orc_edm_expf(-d / c)) + neg * 0.0f);             /* :530 */
             /* (cu - x) > 0  <=>  d < 0 ; (cu - x) <= 0  <=>  d >= 0 */
             const float e = cu - x;
             const float posS = (e > 0.0f) ? 1.0f : 0.0f;
             const float negS = (e <= 0.0f) ? 1.0f : 0.0f;
-            ss = ss + (posS * sa + negS * sb);
+            ss = ss + (posS * (sA[0] - sA[1]) + negS * (((sB1[0] - sB2[0]) - sB1[1]) + sB2[1]));
         }
         float vv = P->I + sv;
         vv = vv * ((vv < 1.0f) ? 1.0f : 0.0f);

@@ -245,3 +245,64 @@ def test_driver_newton_solve_matches_oracle_newton(tmp_path):
     n = lambda f: sum(1 for _ in open(os.path.join(dbg, f)))  # noqa: E731
     assert n("testAverages.dat") == 3000 and n("testAcceptFlag.dat") == 1000 and n("testLift.dat") == 512
     assert n("testAveraged.dat") == 3 and n("testLastSpikeTime.dat") == 3000 and n("test.dat") == 512
+
+
+def _run_driver(tmp_path, name, *args):
+    js = os.path.join(tmp_path, name + ".json")
+    out = subprocess.run([os.path.join(HOST, "driver"), "--json", js, "--quiet", *args], capture_output=True, text=True)
+    return out, json.load(open(js))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_config5_per_gpu_share_newton(tmp_path):
+    """BASELINE configs[4] at one GPU's share: the whole Newton solve of the Driver.cu problem (Driver.cu:15-37,59,
+    69-71; NewtonSolver.cpp:40-197; tol 1e-4, maxIt 10, FD eps 1e-2, damping 1) with R = 125 000 realisations per
+    residual evaluation, EXACT math, the reference's averaging (the driver's defaults).
+
+    * 1024 grid points: same exit flag and iteration count as the oracle-driven Newton iteration on the residual of
+      125 000 identical realisations, history within 5e-6, root within the Newton tolerance;
+    * --dedup (one realisation evolved, replicated) must give the same JSON, field for field, apart from the wall time;
+    * 512 grid points (Driver.cu:69 as shipped): the oracle iteration's exit flag and its first iterates."""
+    _build()
+    R = 125_000
+    Z0 = [float(np.float32(0.3310)), float(np.float32(0.6914)), float(np.float32(1.3557))]
+    out, r = _run_driver(tmp_path, "cfg5_1024", "--real", str(R), "--threads", "1024")
+    assert r["n_real"] == R and r["n_grid"] == 1024 and r["math"] == "exact" and r["mean"] == "reference"
+    p1 = oracle.edm_default_params(n_grid=1024, n_real=1)
+    try:
+        u, hist, it = _newton_on_oracle(p1, Z0, 1e-4, 10, 1e-2, n_real_reference_mean=R)
+        ok = bool(hist[-1] <= 1e-4)
+    except np.linalg.LinAlgError:
+        u, hist, it, ok = None, [], 0, False
+    assert r["converged"] == ok and (out.returncode == 0) == ok, (r, hist)
+    f0, _ = _oracle_f(p1, np.array(Z0), n_real_reference_mean=R)
+    assert np.allclose(r["f0_1024"], f0, rtol=0, atol=2e-7)
+    if hist:
+        assert r["iterations"] == it
+        assert r["residual_evaluations"] == 1 + 4 * it
+        assert np.allclose(r["history"], hist, rtol=0, atol=5e-6)
+        assert np.allclose(r["solution"], u, rtol=0, atol=1e-4)
+    # the opt-in shortcut for sigma = 0 must not change a single digit of the solve
+    out_d, rd = _run_driver(tmp_path, "cfg5_1024_dedup", "--real", str(R), "--threads", "1024", "--dedup")
+    assert out_d.returncode == out.returncode
+    strip = lambda d: {k: v for k, v in d.items() if k != "solve_seconds"}  # noqa: E731
+    assert strip(rd) == strip(r)
+    # Driver.cu:69 as shipped: 512 grid points for the solve
+    out5, r5 = _run_driver(tmp_path, "cfg5_512", "--real", str(R))
+    assert r5["n_grid"] == 512 and r5["n_real"] == R
+    p5 = oracle.edm_default_params(n_grid=512, n_real=1)
+    try:
+        u5, hist5, it5 = _newton_on_oracle(p5, Z0, 1e-4, 10, 1e-2, n_real_reference_mean=R)
+        ok5 = bool(hist5[-1] <= 1e-4)
+    except np.linalg.LinAlgError:
+        u5, hist5, it5, ok5 = None, [], 0, False
+    assert r5["converged"] == ok5 and (out5.returncode == 0) == ok5, (r5, hist5)
+    if hist5 and r5["history"]:
+        n = min(len(hist5), len(r5["history"]))
+        assert np.allclose(r5["history"][:min(n, 3)], hist5[:min(n, 3)], rtol=0, atol=5e-6)
+        if ok5:
+            assert r5["iterations"] == it5 and np.allclose(r5["solution"], u5, rtol=0, atol=1e-4)
+    print("config 5 at the 125k share: %d iterations, |F| = %.3g, %.2f s (dedup %.3f s); 512 points: converged=%s, %.2f s"
+          % (r["iterations"], r["history"][-1] if r["history"] else float("nan"), r["solve_seconds"],
+             rd["solve_seconds"], r5["converged"], r5["solve_seconds"]))
