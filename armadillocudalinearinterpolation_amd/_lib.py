@@ -86,6 +86,7 @@ SIGNATURES = {
     "mi_group_synchronize": (_i32, [_vp]),
     "mi_shard_bounds": (None, [_sz, _i32, _i32, C.POINTER(_sz), C.POINTER(_sz)]),
     "mi_group_set_reduce": (_i32, [_vp, _i32]),
+    "mi_group_rccl_ranks": (_i32, [_vp]),
     "mi_group_grid1_create": (_i32, [_vp, _vp, _vp, _sz, C.c_uint, _pp]),
     "mi_group_grid1_destroy": (_i32, [_vp]),
     "mi_group_interp1_f64_host": (_i32, [_vp, _vp, _vp, _vp, _sz, _dbl]),
@@ -147,8 +148,8 @@ def load(build_if_missing=True, strict=True):
         fn.argtypes = args
     if missing and strict:
         raise RuntimeError("libmi355interp.so lacks symbols declared in mi355_interp.h: %s" % ", ".join(missing))
-    if L.mi_abi_version() != 2:
-        raise RuntimeError("libmi355interp.so ABI version %d != 2" % L.mi_abi_version())
+    if L.mi_abi_version() != 3:
+        raise RuntimeError("libmi355interp.so ABI version %d != 3" % L.mi_abi_version())
     _lib = L
     return L
 

@@ -514,6 +514,10 @@ class _GroupCtx:
     def __init__(self, L, h, device):
         self._L, self._h, self.device = L, h, device
 
+    def timer(self):
+        """HIP events on this member's stream (the stream its shard's kernels are launched on)"""
+        return Timer(self)
+
 
 class Group:
     """One process driving several GPUs: devices = [0, 1, ..] (a repeated ordinal rehearses the sharding on one GPU)."""
@@ -535,6 +539,10 @@ class Group:
 
     def set_reduce(self, mode):
         check(self._L.mi_group_set_reduce(self._h, int(mode)))
+
+    def rccl_ranks(self):
+        """ranks of the group's RCCL communicator as RCCL reports it (ncclCommCount); 0: no communicator possible"""
+        return int(self._L.mi_group_rccl_ranks(self._h))
 
     def synchronize(self):
         check(self._L.mi_group_synchronize(self._h))
@@ -580,18 +588,26 @@ class GroupGrid1:
         check(self._L.mi_group_interp1_f64_host(self._g._h, self._h, _ptr(xq), _ptr(out), xq.size, float(extrap)))
         return out
 
-    def interp_dev(self, xq_shards, extrap=math.nan, gather=False):
+    def interp_dev(self, xq_shards, extrap=math.nan, gather=False, out=None, gathered=None, sync=True):
         """device-resident shards (one float64 tensor per group member, equal sizes); returns the per-shard results and,
-        with gather=True, one buffer per member holding every shard (RCCL all-gather, or device copies in a rehearsal group)"""
+        with gather=True, one buffer per member holding every shard (RCCL all-gather, or device copies in a rehearsal group).
+        out / gathered: caller-owned result tensors (no allocation in the call); sync=False: return with the shards'
+        kernels enqueued on the members' streams (Group.synchronize waits) -- the shape bench.py --backend group times"""
         torch = _torch()
         P, n = len(self._g), int(xq_shards[0].numel())
         assert len(xq_shards) == P and all(int(t.numel()) == n for t in xq_shards)
-        outs = [torch.empty_like(t) for t in xq_shards]
-        full = [torch.empty(P * n, dtype=torch.float64, device=t.device) for t in xq_shards] if gather else None
+        outs = out if out is not None else [torch.empty_like(t) for t in xq_shards]
+        assert len(outs) == P and all(int(t.numel()) == n and t.dtype == torch.float64 and t.is_contiguous() for t in outs)
+        full = gathered
+        if gather and full is None:
+            full = [torch.empty(P * n, dtype=torch.float64, device=t.device) for t in xq_shards]
+        if gather:
+            assert len(full) == P and all(int(t.numel()) == P * n for t in full)
         arr = lambda ts: (C.c_void_p * P)(*[t.data_ptr() for t in ts])  # noqa: E731
         check(self._L.mi_group_interp1_f64_dev(self._g._h, self._h, arr(xq_shards), arr(outs), n, float(extrap),
                                                arr(full) if gather else None))
-        self._g.synchronize()
+        if sync:
+            self._g.synchronize()
         return (outs, full) if gather else outs
 
     def close(self):

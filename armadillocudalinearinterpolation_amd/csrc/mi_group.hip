@@ -42,6 +42,7 @@ struct mi_group {
     ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     std::vector<double*> red_dev;      // MI_EDM partial blocks on the devices (RCCL reduce mode)
 };
 
@@ -85,6 +86,7 @@ mi_status bind_rccl(mi_group* g)
             g->AllGather = (decltype(g->AllGather))dlsym(g->lib, "ncclAllGather");
             g->GroupStart = (decltype(g->GroupStart))dlsym(g->lib, "ncclGroupStart");
             g->GroupEnd = (decltype(g->GroupEnd))dlsym(g->lib, "ncclGroupEnd");
+            g->CommCount = (decltype(g->CommCount))dlsym(g->lib, "ncclCommCount");
         }
     }
     if (!g->lib || !g->CommInitAll || !g->CommDestroy || !g->AllReduce || !g->AllGather || !g->GroupStart || !g->GroupEnd)
@@ -178,6 +180,17 @@ mi_ctx* mi_group_ctx(mi_group* g, int rank)
 {
     if (!g || rank < 0 || rank >= (int)g->ctx.size()) return nullptr;
     return g->ctx[rank];
+}
+
+int mi_group_rccl_ranks(mi_group* g)
+{
+    // the size RCCL itself reports for the group's communicator (ncclCommCount of shard 0's handle), forming the
+    // communicator first if no collective has needed it yet; 0 when the group cannot use RCCL (repeated devices,
+    // library missing) -- the error text is then in mi_last_error(NULL)
+    if (!g || bind_rccl(g) != MI_OK || g->comms.empty() || !g->CommCount) return 0;
+    int n = 0;
+    if (g->CommCount(g->comms[0], &n) != 0) return 0;
+    return n;
 }
 
 mi_status mi_group_set_reduce(mi_group* g, int mode)

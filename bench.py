@@ -7,7 +7,13 @@ arma::interp1-shaped entry point (explicit X, general table).  One "step" = one 
 mi_interp1_f64_dev over the rank's 1e8 resident queries.  Inputs are generated in HBM before timing.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N)
+  N > 1, either launched by the driver as
+      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+  or invoked plainly (no WORLD_SIZE in the environment): this process then touches neither torch nor the GPU, starts that
+  same launcher as a CHILD process (one rank per GPU), relays its output and exits with its code.
+  --backend group: ONE process drives the N GPUs through the C ABI's mi_group_* entry points (csrc/mi_group.hip: one
+  context + stream per device, RCCL bound by dlopen); the JSON line gains "rccl_ranks", the size of the ncclCommInitAll
+  communicator as RCCL reports it.
 
 Multi-GPU: the query axis shards trivially: every rank owns its own 1e8-query shard and a
 replica of the table; there is no data-path collective in the timed region ("scaling": "weak").  The optional
@@ -59,6 +65,12 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (process group, barriers, all-reduce of the timings, all-gather) with a "
                          "world of ONE rank: rehearsal of the RCCL calls on a one-GPU box")
+    ap.add_argument("--backend", choices=["ranks", "group"], default="ranks",
+                    help="ranks (default): one process per GPU, torch.distributed over RCCL; group: one process, the C ABI's "
+                         "mi_group_create(N) + mi_group_interp1_f64_dev on device-resident shards")
+    ap.add_argument("--gather", action="store_true",
+                    help="--backend group: also reassemble the whole result vector on every GPU inside the timed step "
+                         "(gathered_dev of mi_group_interp1_f64_dev: an RCCL all-gather over xGMI behind the kernels)")
     ap.add_argument("--config", type=int, choices=[2, 3], default=2,
                     help="2 (default): BASELINE configs[1], the 1-D headline; 3: configs[2], 4096^2 bilinear, 1e8 scattered "
                          "queries as the timed workload (for profiling interp2_kernel; same JSON contract)")
@@ -190,8 +202,104 @@ def bench_config3(args, ctx, info, dev, world, rank, barrier, dist, dist_on):
         dist.destroy_process_group()
 
 
+def self_launch(args):
+    """--gpus N > 1 invoked without a launcher: start `torch.distributed.run` (one rank per GPU) as a child process, relay
+    what it prints (rank 0's JSON line stays the last line of stdout) and return its exit code.  This parent imports
+    neither torch nor the package and never touches the GPU; nothing is exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                       # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            line = ln.rstrip("\n")                    # held back so that it is the LAST line whatever the ranks print after it
+        else:
+            sys.stdout.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc
+
+
+def bench_group(args):
+    """One host process, N GPUs, through the C ABI only (include/mi355_interp.h "several GPUs of one node"):
+    mi_group_create(N), the table replicated by mi_group_grid1_create, one step = ONE mi_group_interp1_f64_dev call over
+    N device-resident shards of --nq queries each (every shard's kernel on its own device and stream, concurrently).
+    Timed region: mi_group_synchronize on both sides (= every device idle), K steps in between; value = N * nq * K / wall."""
+    import torch
+
+    import armadillocudalinearinterpolation_amd as mi
+    from armadillocudalinearinterpolation_amd import synth
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU: the hot path has no CPU fallback", file=sys.stderr)
+        return 2
+    n = args.gpus
+    devices = [0] * n if args.rehearse_one_device else list(range(n))
+    grp = mi.Group(devices)
+    rccl_ranks = grp.rccl_ranks()                     # forms the ncclCommInitAll communicator (0: repeated devices)
+    X, Y = synth.config_grid(args.ng)
+    tab = grp.grid1(X, Y, sanitise=False)
+    nq = args.nq - (args.nq & 1)
+    xq = [synth.splitmix_uniform(SEED_Q + 0x1000 * r, nq, torch.device("cuda", devices[r])) for r in range(n)]
+    yq = [torch.empty_like(x) for x in xq]
+    full = [torch.empty(n * nq, dtype=torch.float64, device=x.device) for x in xq] if args.gather else None
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    step = lambda: tab.interp_dev(xq, out=yq, gather=args.gather, gathered=full, sync=False)  # noqa: E731
+    for _ in range(args.warmup):
+        step()
+    grp.synchronize()
+    timers = [grp.ctx(r).timer() for r in range(n)]
+    t0 = time.perf_counter()
+    for tm in timers:
+        tm.start()
+    for _ in range(args.steps):
+        step()
+    for tm in timers:
+        tm.stop()
+    grp.synchronize()
+    wall = time.perf_counter() - t0
+    ev = max(tm.elapsed_ms() for tm in timers) * 1e-3
+    info = mi.Context(devices[0]).device_info()
+    table_bytes = 8.0 * (args.ng + 1)
+    alg = 16.0 * nq + table_bytes
+    ks = ev / args.steps
+    print(json.dumps({
+        "metric": "interpolated points/sec (fp64)", "value": n * nq * args.steps / wall, "unit": "points/s",
+        "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "backend": "group", "rccl_ranks": rccl_ranks,
+        "config": {"workload": "1D linear interp, %.0e random queries per GPU on %.0e-point grid, fp64 (BASELINE configs[1])" % (nq, args.ng),
+                   "queries_per_gpu": nq, "grid_nodes": args.ng, "table": "general",
+                   "entry_point": "mi_group_interp1_f64_dev" + (" + gathered_dev (ncclAllGather)" if args.gather else ""),
+                   "sharding": "queries/%d, table replicated by mi_group_grid1_create, %s" % (
+                       n, "RCCL all-gather of the result shards in the step" if args.gather else "no collective"),
+                   "devices": devices},
+        "roofline": {"bound": "hbm", "achieved": alg / ks / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": alg / ks / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "per device: the kernel mi_interp1_f64_dev picks for its shard",
+                     "kernel_ms": ks * 1e3, "algorithmic_bytes_per_launch": alg,
+                     "note": "slowest device's HIP-event time per step (events on each member's own stream)"},
+        "cpu_baseline": None, "device": info["name"]}), flush=True)
+    tab.close()
+    grp.close()
+    return 0
+
+
 def main():
     args = parse()
+    if args.backend == "group":
+        sys.exit(bench_group(args))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_dist:
+        sys.exit(self_launch(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -206,9 +314,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     dist_on = world > 1 or args.force_dist
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus,
-              file=sys.stderr)
+    if args.gpus > 1 and world != args.gpus:
+        print("bench.py --gpus %d inside a world of %d ranks: launch one rank per GPU" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the hot path has no CPU fallback", file=sys.stderr)

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MI355_INTERP_ABI_VERSION 2
+#define MI355_INTERP_ABI_VERSION 3
 
 typedef int mi_status;
 enum {
@@ -321,6 +321,10 @@ void mi_shard_bounds(size_t n, int rank, int world, size_t* lo, size_t* hi);
 #define MI_GROUP_REDUCE_HOST 0
 #define MI_GROUP_REDUCE_RCCL 1
 mi_status mi_group_set_reduce(mi_group* g, int mode);
+/* Number of ranks of the group's RCCL communicator as RCCL reports it (ncclCommCount; the communicator is formed by
+ * ncclCommInitAll on first use, here if need be).  0: the group cannot use RCCL (a device named twice, or librccl
+ * missing); mi_last_error(NULL) says why.  bench.py --backend group prints it as "rccl_ranks". */
+int mi_group_rccl_ranks(mi_group* g);
 
 /* 1-D table replicated on every device of the group (x, y: host pointers; flags as mi_grid1_create). */
 mi_status mi_group_grid1_create(mi_group* g, const double* x, const double* y, size_t n, unsigned flags,
