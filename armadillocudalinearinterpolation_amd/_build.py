@@ -45,15 +45,38 @@ def is_stale():
 
 
 def build_lib(force=False, verbose=False):
-    """Compile csrc/*.hip -> libmi355interp.so with hipcc (cross-compiles without a GPU)."""
+    """Compile csrc/*.hip -> libmi355interp.so with hipcc (cross-compiles without a GPU): one object per translation
+    unit, compiled in parallel (csrc/build/, git-ignored), then one link."""
     if not force and not is_stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libmi355interp.so cannot be built (there is no CPU fallback)")
+    from concurrent.futures import ThreadPoolExecutor
     extra = os.environ.get("MI_EXTRA_HIPCC_FLAGS", "").split()
-    cmd = [hipcc] + HIPCC_FLAGS + extra + ["-I", os.path.join(REPO_ROOT, "include"), "-I", CSRC,
-                                   "-o", LIB_PATH + ".tmp"] + sources()
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + extra + ["-I", os.path.join(REPO_ROOT, "include"), "-I", CSRC]
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(p) for p in _deps() if not p.endswith(".hip"))
+    stamp = " ".join(flags)
+    stamp_path = os.path.join(objdir, "flags.txt")
+    same_flags = os.path.exists(stamp_path) and open(stamp_path).read() == stamp
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        if (not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+                and os.path.getmtime(obj) > hdr_t):
+            return obj
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    open(stamp_path, "w").write(stamp)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

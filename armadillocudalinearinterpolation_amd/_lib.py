@@ -48,7 +48,6 @@ _pp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "mi_abi_version": (_i32, []),
     "mi_debug_pinned_ranges": (_sz, []),
-    "mi_debug_sweep_timing": (_i32, [_vp, _vp]),
     "mi_last_error": (C.c_char_p, [_vp]),
     "mi_ctx_create": (_i32, [_i32, _pp]),
     "mi_ctx_destroy": (_i32, [_vp]),

@@ -622,6 +622,9 @@ struct mi_edm {
     uint16_t seed_ind[kMaxSpikes] = {0};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};
+    // test / tuning hooks, read from the environment ONCE per handle (mi_edm_create), never per launch:
+    int waves_per_real = 0;            // MI_EDM_WAVES_PER_REALISATION = 1 | 4 forces an evolve kernel form (0: by realisation count)
+    bool no_uniform_div = false;       // MI_EDM_NO_UNIFORM_DIV: never take the exact quotient by wave-uniform divisors
 };
 
 namespace {
@@ -761,13 +764,9 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd)
         accept = (uint32_t*)(e->d_one + kOneAccept);
     }
     // Few realisations: spread each one over a workgroup of 4 waves (evolve_wg_kernel, bit-identical results).
-    // MI_EDM_WAVES_PER_REALISATION = 1 | 4 overrides the choice (test / tuning hook).
+    // MI_EDM_WAVES_PER_REALISATION = 1 | 4 (read at mi_edm_create) overrides the choice (test / tuning hook).
     const unsigned Reff = M.R;
-    int wpr = (Reff < kWgNarrow) ? 4 : 1;
-    if (const char* env = getenv("MI_EDM_WAVES_PER_REALISATION")) {
-        const int v = atoi(env);
-        if (v == 1 || v == 4) wpr = v;
-    }
+    const int wpr = e->waves_per_real ? e->waves_per_real : ((Reff < kWgNarrow) ? 4 : 1);
     const bool three = e->p.n_spikes <= 3;
     if (wpr == 1) {
 #define MI_EVOLVE(H, NS, UD)                                                                                      \
@@ -777,7 +776,7 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd)
         // the LDS leaving six or more per SIMD (N <= 640) and the launch bringing three or more.  N = 512: R = 16384
         // 10.25 -> 9.00 ms, R = 4000 3.10 -> 2.91 ms, but R = 1000 (one wave per SIMD) 1.59 -> 2.10 ms.
         const unsigned cus = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256);
-        const bool udiv = MATH == 0 && !hetero && per_cu >= 6 && Reff >= cus * 12u && getenv("MI_EDM_NO_UNIFORM_DIV") == nullptr;
+        const bool udiv = MATH == 0 && !hetero && per_cu >= 6 && Reff >= cus * 12u && !e->no_uniform_div;
         if (hetero) { if (three) MI_EVOLVE(true, 3, false); else MI_EVOLVE(true, kMaxSpikes, false); }
         else if (udiv) { if (three) MI_EVOLVE(false, 3, true); else MI_EVOLVE(false, kMaxSpikes, true); }
         else { if (three) MI_EVOLVE(false, 3, false); else MI_EVOLVE(false, kMaxSpikes, false); }
@@ -873,6 +872,11 @@ mi_status mi_edm_create(mi_ctx* ctx, const mi_edm_params* p, mi_edm** out)
     e->device = ctx->device;
     e->p = *p;
     fill_model(e->p, &e->M);
+    if (const char* env = getenv("MI_EDM_WAVES_PER_REALISATION")) {
+        const int v = atoi(env);
+        if (v == 1 || v == 4) e->waves_per_real = v;
+    }
+    e->no_uniform_div = getenv("MI_EDM_NO_UNIFORM_DIV") != nullptr;
     hipError_t err = hipSuccess;
     if (err == hipSuccess) err = hipMalloc(&e->d_v, kMaxGrid * sizeof(float));
     if (err == hipSuccess) err = hipMalloc(&e->d_s, kMaxGrid * sizeof(float));

@@ -77,10 +77,6 @@ int mi_abi_version(void);
 /* Test hook: number of caller host ranges the library currently keeps page-locked on behalf of host-convenience calls
  * in flight (mi_interp1_f64_host, mi_interp2_f64_host); 0 once every such call has returned, on success or error. */
 size_t mi_debug_pinned_ranges(void);
-/* Test / profiling hook: phase timing of the pipelined region-sweep kernel.  ticks_dev: device array of
- * [workgroups][2 groups][2 roles: gather, prepare][6 schedule intervals] 64-bit counters (wall_clock64, 100 MHz) that the
- * kernel overwrites at the end of every launch; NULL switches the stamps off again (the default). */
-mi_status mi_debug_sweep_timing(mi_ctx* ctx, unsigned long long* ticks_dev);
 /* Hint about the order of the query vectors handed to mi_interp1_f64_dev on this context.  Unordered queries
  * over a table larger than L2 are processed by a "region sweep" kernel (workgroup-local ordering by table region
  * in LDS; results keep the caller's order), ordered/clustered ones by the plain streaming kernel.  AUTO decides on

@@ -17,7 +17,7 @@ Z_DRIVER = [0.3310, 0.6914, 1.3557]
 def evolve_form(request, monkeypatch):
     """The evolve kernel has two forms (one wave, or a workgroup of four waves, per realisation) chosen by the
     realisation count; every test of this file runs with the automatic choice and with each form forced
-    (MI_EDM_WAVES_PER_REALISATION, read at launch time), so both are held to the same bit-exact parity."""
+    (MI_EDM_WAVES_PER_REALISATION, read when an EventDrivenMap handle is created), so both are held to the same bit-exact parity."""
     if request.param == "auto":
         monkeypatch.delenv("MI_EDM_WAVES_PER_REALISATION", raising=False)
     else:
