@@ -8,8 +8,9 @@ import sys
 
 
 def find(d, pat):
+    """the NEWEST file under d that matches (a directory that was not cleared between runs may hold several)"""
     r = glob.glob(os.path.join(d, "**", pat), recursive=True)
-    return r[0] if r else None
+    return max(r, key=os.path.getmtime) if r else None
 
 
 def kernel_durations(trace_csv):
@@ -44,6 +45,8 @@ def main():
     st = find(os.path.join(out_dir, "stats"), "*kernel_stats.csv")
     if st:
         summary["kernel_stats_csv"] = open(st).read()
+        # the stand-alone copy for profiles/ comes from the SAME file the summary quotes
+        open(os.path.join(out_dir, "kernel_stats_%s.csv" % tag), "w").write(summary["kernel_stats_csv"])
     pm = {}
     for sub in ("pmc_fetch", "pmc_write", "pmc_tcc", "pmc_tcc2"):
         f = find(os.path.join(out_dir, sub), "*counter_collection.csv")
@@ -105,6 +108,12 @@ def main():
                           "tallies every fabric read at 64 B): reads = 128*TCC_EA0_RDREQ_128B + 64*_64B + 32*_32B, writes = "
                           "WRITE_SIZE*1024; without the size classes the 'doubled' figure (2*FETCH_SIZE + WRITE_SIZE)*1024; "
                           "Infinity-Cache hits are counted"}
+    if latest and st:
+        # the kernel the traffic figure belongs to must be the dominant kernel of the kernel-stats CSV committed with it
+        rows = list(csv.DictReader(open(st)))
+        top = max(rows, key=lambda r: float(r["TotalDurationNs"]))["Name"]
+        for e in latest.values():
+            assert e["kernel"] == top, "traffic_latest names %r but the dominant kernel of %s is %r" % (e["kernel"], st, top)
     if latest:
         # stamp: the sources the profiled library was built from (bench.py quotes the figure only for the same build)
         try:

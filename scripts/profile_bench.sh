@@ -8,6 +8,9 @@ TAG=${1:-r01}
 QUERIES=${2:-random}        # random | sorted | uniform (bench.py --queries)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
+# a previous run's CSVs under the same tag must not be picked up by the parser (round 2 committed a stale kernel_stats.csv
+# that way): every pass starts from an empty directory
+rm -rf "$OUT/stats" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_tcc" "$OUT/pmc_tcc2"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$REPO"
