@@ -350,6 +350,94 @@ def test_scattered_bilinear_seeded(mi_ctx):
     assert _eq(grid.interp(_t(xq), _t(yq)).cpu().numpy(), oracle.interp2_bilinear(xg, yg, Z, xq, yq, nthreads=4))
 
 
+@pytest.fixture
+def ordered_path(mi_ctx):
+    """force mi_interp2_f64_dev onto the call-wide cell ordering for the duration of a test"""
+    import armadillocudalinearinterpolation_amd as mi
+    mi_ctx.set_interp2_path(mi.INTERP2_ORDERED)
+    yield mi_ctx
+    mi_ctx.set_interp2_path(mi.INTERP2_AUTO)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("shape", [(257, 129), (64, 1500), (3000, 2), (2, 2)])
+def test_ordered_bilinear_path_is_the_direct_kernel_bit_for_bit(ordered_path, shape, compact):
+    """The three-pass path (order by table block, evaluate block by block, un-order) runs the direct kernel's eval2 on every
+    query: same bits as the direct kernel AND as the oracle, on uniform axes and on explicit axes with a linear coarse
+    index, both resident layouts, with out-of-range / NaN / node-exact queries, a ragged tail and a workspace smaller than
+    the call (several passes)."""
+    import armadillocudalinearinterpolation_amd as mi
+    ctx = ordered_path
+    nx, ny = shape
+    nq = 5 * 4096 + 1237                                   # five tiles and a ragged tail
+    rng = np.random.default_rng(nx * 1000 + ny)
+    jx, jy = rng.random(nx) * 0.3, rng.random(ny) * 0.3
+    xg = (np.arange(nx) + jx) / nx * 2.0 - 0.5             # explicit, within a third of a cell of a line: guess + walk
+    yg = (np.arange(ny) + jy) / ny * 3.0 + 1.0
+    Z = np.sin(3 * xg)[None, :] * np.cos(2 * yg)[:, None] + 0.1 * rng.random((ny, nx))
+    xq = rng.random(nq) * (xg[-1] - xg[0]) * 1.04 + xg[0] - 0.02 * (xg[-1] - xg[0])
+    yq = rng.random(nq) * (yg[-1] - yg[0]) * 1.04 + yg[0] - 0.02 * (yg[-1] - yg[0])
+    xq[:6] = [xg[0], xg[-1], xg[nx // 2], xg[-1], np.nan, xg[1]]
+    yq[:6] = [yg[0], yg[-1], yg[-1], yg[ny // 2], yg[1], np.inf]
+    xq[4096:4096 + nx] = xg                                 # a pile of node-exact abscissae in the second tile
+    ref = oracle.interp2_bilinear(xg, yg, Z, xq, yq, nthreads=4)
+    grid = mi.Grid2.from_axes(ctx, xg, yg, Z, compact=compact)
+    assert grid.info()["workspace_queries"] == 0            # no workspace: ORDERED falls back to the direct kernel ...
+    direct = grid.interp(_t(xq), _t(yq)).cpu().numpy()
+    assert _eq(direct, ref)
+    grid.reserve(nq)                                        # ... until the caller reserves one
+    info = grid.info()
+    assert info["workspace_queries"] >= nq and info["ordered_blocks"] >= 1
+    assert _eq(grid.interp(_t(xq), _t(yq)).cpu().numpy(), ref)
+    grid.reserve(2 * 4096)                                  # smaller than the call: three passes + the tail
+    assert _eq(grid.interp(_t(xq), _t(yq)).cpu().numpy(), ref)
+    grid.reserve(0)
+    assert grid.info()["workspace_queries"] == 0
+    grid.close()
+    # uniform axes (implicit nodes)
+    gu = mi.Grid2.uniform(ctx, -0.5, 2.0 / nx, nx, 1.0, 3.0 / ny, ny, Z, compact=compact).reserve(nq)
+    want = oracle.interp2_bilinear_uniform(-0.5, 2.0 / nx, nx, 1.0, 3.0 / ny, ny, Z, xq, yq, nthreads=4)
+    assert _eq(gu.interp(_t(xq), _t(yq)).cpu().numpy(), want)
+    gu.close()
+
+
+def test_ordered_bilinear_path_many_blocks_and_skewed_queries(ordered_path):
+    """A 2048 x 1536 table has 48 blocks of the ordering in the quad layout; queries piled into one corner (every tile
+    almost empty for most blocks), onto one grid line, and spread evenly must all come out as the oracle's."""
+    import armadillocudalinearinterpolation_amd as mi
+    ctx = ordered_path
+    nx, ny, nq = 1536, 2048, 40 * 4096
+    rng = np.random.default_rng(7)
+    Z = rng.random((ny, nx))
+    g = mi.Grid2.uniform(ctx, 0.0, 1.0 / (nx - 1), nx, 0.0, 1.0 / (ny - 1), ny, Z).reserve(nq)
+    assert g.info()["ordered_blocks"] == 48
+    for kind in ("even", "corner", "line"):
+        xq, yq = rng.random(nq), rng.random(nq)
+        if kind == "corner":
+            xq, yq = xq * 0.01, 1.0 - yq * 0.01
+        elif kind == "line":
+            xq[:] = 700.0 / (nx - 1)
+        ref = oracle.interp2_bilinear_uniform(0.0, 1.0 / (nx - 1), nx, 0.0, 1.0 / (ny - 1), ny, Z, xq, yq, nthreads=8)
+        assert _eq(g.interp(_t(xq), _t(yq)).cpu().numpy(), ref), kind
+    g.close()
+
+
+def test_binary_search_axes_keep_the_direct_kernel(ordered_path):
+    """an axis without a linear coarse index (strongly non-uniform: binary search) cannot be ordered by block: reserve()
+    succeeds, reserves nothing, and the call takes the direct kernel"""
+    import armadillocudalinearinterpolation_amd as mi
+    nx, ny, nq = 257, 129, 3 * 4096
+    xg = np.cumsum(oracle.splitmix_uniform(1, nx) + 0.01)
+    yg = np.cumsum(oracle.splitmix_uniform(2, ny) ** 3 + 1e-4)
+    Z = np.sin(xg)[None, :] * np.cos(3 * yg)[:, None]
+    q = oracle.splitmix_uniform(3, 2 * nq)
+    xq, yq = q[:nq] * (xg[-1] - xg[0]) + xg[0], q[nq:] * (yg[-1] - yg[0]) + yg[0]
+    grid = mi.Grid2.from_axes(ordered_path, xg, yg, Z).reserve(nq)
+    assert grid.info()["workspace_queries"] == 0 and grid.info()["ordered_blocks"] == 0
+    assert _eq(grid.interp(_t(xq), _t(yq)).cpu().numpy(), oracle.interp2_bilinear(xg, yg, Z, xq, yq, nthreads=4))
+    grid.close()
+
+
 # ---------------------------------------------------------------- BASELINE-size property tests
 def test_config2_full_size_properties(mi_ctx):
     """1e8 random queries over a 1e6-node table (BASELINE.json configs[1]), the very query set bench.py times
@@ -490,7 +578,19 @@ def test_config3_full_grid_sampled(mi_ctx):
     NQ = 100_000_000
     q2 = synth.splitmix_uniform(0x5EED0004, 2 * NQ, torch.device("cuda", 0))
     xq, yq = q2[:NQ], q2[NQ:]
-    out = grid.interp(xq, yq)
+    assert grid.info()["workspace_queries"] == 0 and grid.info()["ordered_blocks"] == 256
+    out = grid.interp(xq, yq)                              # AUTO: the direct gather kernel
+    grid.reserve(NQ)
+    mi_ctx.set_interp2_path(mi.INTERP2_ORDERED)
+    try:
+        ordered = grid.interp(xq, yq)                      # the call-wide cell ordering on the same 1e8 queries
+        assert torch.equal(out.view(torch.int64), ordered.view(torch.int64))
+        del ordered
+        grid.reserve(30_000_000)                           # a workspace smaller than the call: four passes
+        assert torch.equal(grid.interp(xq, yq), out)
+    finally:
+        mi_ctx.set_interp2_path(mi.INTERP2_AUTO)
+    grid.reserve(0)
     compact = mi.Grid2.uniform(mi_ctx, 0.0, 1.0 / (n - 1), n, 0.0, 1.0 / (n - 1), n, Z, compact=True)
     assert torch.equal(compact.interp(xq, yq), out)
     compact.close()
