@@ -321,6 +321,26 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 if (edm::will_fire<MATH, UDIV && !HETERO>(M, vv, sn, bk)) pend |= (1u << k);   // (padding lanes: masked below)
             }
             pend &= valid;
+            if (events == 1u) {
+                // A neuron whose s starts NaN but whose v starts finite (the lift profile poisons s over a longer stretch than v:
+                // from neuron 820 and 857 of 1024 at the reference's parameters) has BOTH NaN after its first update (the
+                // division of so * e1 carries the NaN into v) and, like the neurons that start that way, for ever after.  So the
+                // set of all-NaN slices is final now: one more look, and the slices that joined it (one of sixteen at the
+                // reference's parameters) are skipped from the second event on.  Same rule as at t = 0: the slice's standing
+                // arg-min candidate (kNever at the lane's lowest index in a skipped slice) stays in nan_i.
+                for (unsigned k = 0; k < npl; ++k) {
+                    if ((skip >> k) & 1u) continue;
+                    const unsigned i = k * 64u + lane;
+                    const bool act = i < M.N;
+                    const float vi = V[i], si = S[i];
+                    if (__all(!act || (vi != vi && si != si)) && __any(act)) {
+                        skip |= 1u << k;
+                        valid &= ~(1u << k);
+                        if (act && i < nan_i) nan_i = i;
+                    }
+                }
+                pend &= valid;
+            }
             lowest_quiet();
             MI_EV_STAMP(2)
             now = now + dt;

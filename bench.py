@@ -140,11 +140,12 @@ def measured_traffic(mode, queries, nq):
         e = t.get("interp1_mode%d_%s" % (mode, queries))
         if e and int(e.get("nq", 0)) == int(nq):
             if e.get("source_sha256") != _build.source_hash():
-                return None, "profiles/traffic_latest.json was measured on another build of the kernels (source hash differs): not quoted"
-            return e["hbm_bytes_per_launch"], "rocprofv3 PMC passes of this build (scripts/profile_bench.sh), profiles/traffic_latest.json"
+                return None, "profiles/traffic_latest.json was measured on another build of the kernels (source hash differs): not quoted", {}
+            l2 = {k: e[k] for k in ("tcc_req_per_launch", "gpu_clock_hz", "l2_request_bound_ms", "tcc_busy_frac") if k in e}
+            return e["hbm_bytes_per_launch"], "rocprofv3 PMC passes of this build (scripts/profile_bench.sh), profiles/traffic_latest.json", l2
     except (OSError, ValueError, KeyError):
         pass
-    return None, "no committed PMC profile covers this configuration"
+    return None, "no committed PMC profile covers this configuration", {}
 
 
 def kernel_label(args, ginfo, nq, info):
@@ -394,7 +395,7 @@ def main():
     alg_bytes = 16.0 * nq + float(ginfo["table_bytes"])                              # per launch, per GPU
     kernel_s = ev / args.steps                                                        # this rank's avg launch
     achieved = alg_bytes / kernel_s / 1e9
-    traffic, traffic_note = measured_traffic(ginfo["mode"], args.queries, nq)
+    traffic, traffic_note, l2 = measured_traffic(ginfo["mode"], args.queries, nq)
     result = {
         "metric": "interpolated points/sec (fp64)",
         "value": (args.nq if (strong and not args.shard_of) else world * nq) * args.steps / wall_max,
@@ -426,6 +427,16 @@ def main():
         },
         "device": info["name"],
     }
+    if l2.get("l2_request_bound_ms"):
+        # the resource that binds the random-query kernel: every query is one request to the XCD L2s,
+        # which serve at most one request per channel per clock.  Requests per launch from the stamped PMC profile of this
+        # build; the fraction is against THIS run's kernel time.
+        result["roofline"]["l2_request_bound_ms"] = l2["l2_request_bound_ms"]
+        result["roofline"]["l2_request_frac"] = l2["l2_request_bound_ms"] / (kernel_s * 1e3)
+        result["roofline"]["l2_requests_per_launch"] = l2["tcc_req_per_launch"]
+        result["roofline"]["l2_note"] = ("TCC_REQ per launch / (128 L2 channels x %.2f GHz measured clock): the time the XCD L2s need "
+                                         "for the launch's requests at one per channel-clock; profiled TCC_BUSY fraction %.2f"
+                                         % (l2["gpu_clock_hz"] * 1e-9, l2.get("tcc_busy_frac") or float("nan")))
 
     extra = {}
     if rank == 0 and not args.no_extra:

@@ -4,6 +4,13 @@
 // group that has just scattered its tile into LDS waits for that at barrier C before it starts its gather rounds.  Only the
 // scattering group's own eight waves need to agree that the tile is in: here C is a barrier among those waves only, and the
 // rounds start while the other group is still issuing.  VARIANT 0 = the product schedule (control), 1 = no barrier C.
+//
+// VARIANT 2 (time slots): the CUs of an XCD in two halves (parity of blockIdx / 8) that take turns on the L2: the gather
+// rounds of a tile are cut into four quarters, and a quarter only starts inside a time slot of the workgroup's parity
+// (slot = global 100 MHz clock / TAU ticks, the same on every CU: no communication).  Question: if only half of an XCD's
+// CUs gather at any moment, do they gather twice as fast (the L2 request rate being what bounds the rounds), so that the
+// other half of the time is free for the streams?  VARIANT 3: same slots, every workgroup parity 0 (control: all gather
+// in the even slots and nobody in the odd ones).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I armadillocudalinearinterpolation_amd/csrc \
 //         -o scripts/exp_pipe2 scripts/exp_pipe2.hip
 #include <hip/hip_runtime.h>
@@ -17,6 +24,18 @@
 #include "mi_interp1_sweep.hpp"
 
 using namespace mi_interp1;
+
+#ifndef TAU
+#define TAU 256          // slot length in 100 MHz ticks (256 = 2.56 us)
+#endif
+__device__ __forceinline__ void wait_slot(unsigned parity)
+{
+    for (;;) {
+        const unsigned long long t = wall_clock64();
+        if ((unsigned)((t / TAU) & 1ull) == parity) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -85,6 +104,8 @@ __global__ __launch_bounds__(kPipeThreads) void pipe2_kernel(G1Dev g, const doub
         if (act) {
 #pragma unroll 1
             for (int iv = 0; iv < 4; ++iv) { // eight rounds; the other group prepares its tile meanwhile
+                if (VARIANT == 2) wait_slot((blockIdx.x >> 3) & 1u);
+                if (VARIANT == 3) wait_slot(0u);
                 pipe_gather_rounds<MODE, FORMULA>(g, sq, first, stride, extrap);
                 first += 8 * stride;
             }
@@ -115,7 +136,7 @@ __global__ __launch_bounds__(kPipeThreads) void pipe2_kernel(G1Dev g, const doub
 #pragma unroll
             for (int u = 0; u < kSweepK; ++u) q[u] = 0.0;
         }
-        if (VARIANT == 0) pipe_barrier();   // C (product form): wait until the other group's tile is in
+        if (VARIANT != 1) pipe_barrier();   // C (product form): wait until the other group's tile is in
     };
     auto prep_step = [&](long it) {          // this group owns tile it+1 (past the last tile: barriers only)
         const bool act = it + 1 < nloc;
@@ -176,7 +197,7 @@ __global__ __launch_bounds__(kPipeThreads) void pipe2_kernel(G1Dev g, const doub
                 if ((u & 6) == 6) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (VARIANT == 0) pipe_barrier();   // C (product form)
+        if (VARIANT != 1) pipe_barrier();   // C (product form)
         else group_barrier();               // only the scattering group waits for its own scatter; the other group is still issuing stores / loads
     };
     if (grp == 0) {
@@ -260,6 +281,13 @@ int main(int argc, char** argv)
         printf("%-58s %.4f ms (min %.4f, max %.4f)  %.1f %% of 8 TB/s\n", name, ts[3], ts[0], ts[6], (16.0 * nq + 8e6) / (ts[3] * 1e-3) / 8e12 * 100);
         return ts[3];
     };
+    time("VARIANT 2: quarter-rounds in alternating time slots (two halves of each XCD)", [&] {
+        hipLaunchKernelGGL((pipe2_kernel<0, 3, 2>), dim3(256), dim3(kPipeThreads), 0, 0, g, xq, yb, ntiles, __builtin_nan(""), bscale, flag, (size_t)0, ProbeArgs{});
+    });
+    time("VARIANT 3: quarter-rounds in the even slots only, every CU (control)", [&] {
+        hipLaunchKernelGGL((pipe2_kernel<0, 3, 3>), dim3(256), dim3(kPipeThreads), 0, 0, g, xq, yb, ntiles, __builtin_nan(""), bscale, flag, (size_t)0, ProbeArgs{});
+    });
+    printf("TAU = %d ticks = %.2f us\n", TAU, TAU * 0.01);
     float t[2][2];
     for (int rep = 0; rep < 2; ++rep) {     // alternate the two forms: box-to-box and run-to-run drift is a few per cent
         t[rep][0] = time("VARIANT 0: product schedule (barrier C for all 16 waves)", [&] {

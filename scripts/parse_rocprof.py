@@ -48,7 +48,7 @@ def main():
         # the stand-alone copy for profiles/ comes from the SAME file the summary quotes
         open(os.path.join(out_dir, "kernel_stats_%s.csv" % tag), "w").write(summary["kernel_stats_csv"])
     pm = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_tcc", "pmc_tcc2"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_tcc", "pmc_tcc2", "pmc_tcc3", "pmc_clk"):
         f = find(os.path.join(out_dir, sub), "*counter_collection.csv")
         if not f:
             continue
@@ -108,6 +108,23 @@ def main():
                           "tallies every fabric read at 64 B): reads = 128*TCC_EA0_RDREQ_128B + 64*_64B + 32*_32B, writes = "
                           "WRITE_SIZE*1024; without the size classes the 'doubled' figure (2*FETCH_SIZE + WRITE_SIZE)*1024; "
                           "Infinity-Cache hits are counted"}
+    # the L2 request roofline of the dominant kernel: requests served per launch / (128 channels x one request per clock)
+    if dom and dom in pm and "TCC_REQ_sum" in pm[dom]:
+        req = pm[dom]["TCC_REQ_sum"]["per_dispatch_median"]
+        dur_us = summary["kernels"][dom]["median_us"]
+        clk = None
+        if "GRBM_GUI_ACTIVE" in pm[dom]:
+            # summed over the eight XCD instances by counters(); a launch keeps every XCD busy for its whole duration
+            c = pm[dom]["GRBM_GUI_ACTIVE"]["per_dispatch_median"] / 8.0 / (dur_us * 1e-6)
+            clk = c if 1.5e9 < c < 2.7e9 else None
+        clk = clk or 2.4e9
+        l2 = {"tcc_req_per_launch": req, "gpu_clock_hz": clk, "l2_channels": 128,
+              "l2_request_bound_ms": req / (128.0 * clk) * 1e3,
+              "tcc_busy_frac": (pm[dom]["TCC_BUSY_sum"]["per_dispatch_median"] / (128.0 * clk * dur_us * 1e-6)) if "TCC_BUSY_sum" in pm[dom] else None}
+        summary["l2_request_roofline"] = {dom: l2}
+        for e in latest.values():
+            if e["kernel"] == dom:
+                e.update(l2)
     if latest and st:
         # the kernel the traffic figure belongs to must be the dominant kernel of the kernel-stats CSV committed with it
         rows = list(csv.DictReader(open(st)))

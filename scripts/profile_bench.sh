@@ -10,7 +10,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 # a previous run's CSVs under the same tag must not be picked up by the parser (round 2 committed a stale kernel_stats.csv
 # that way): every pass starts from an empty directory
-rm -rf "$OUT/stats" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_tcc" "$OUT/pmc_tcc2"
+rm -rf "$OUT/stats" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_tcc" "$OUT/pmc_tcc2" "$OUT/pmc_tcc3" "$OUT/pmc_clk"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$REPO"
@@ -27,4 +27,9 @@ echo "pmc tcc rc=$?"
 # size classes of the L2's fabric reads: the bytes that really left L2 (FETCH_SIZE tallies every request at 64 B)
 rocprofv3 --pmc TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace --output-format csv -d "$OUT/pmc_tcc2" -- python3 $ARGS > "$OUT/pmc_tcc2.log" 2>&1
 echo "pmc tcc2 rc=$?"
+# the L2's own load: requests it served and the cycles its channels were busy; GPU clock cycles of the launch (-> clock rate)
+rocprofv3 --pmc TCC_REQ_sum TCC_BUSY_sum --kernel-trace --output-format csv -d "$OUT/pmc_tcc3" -- python3 $ARGS > "$OUT/pmc_tcc3.log" 2>&1
+echo "pmc tcc3 rc=$?"
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_clk" -- python3 $ARGS > "$OUT/pmc_clk.log" 2>&1
+echo "pmc clk rc=$?"
 python3 scripts/parse_rocprof.py "$OUT" "$TAG" "$QUERIES"
