@@ -28,6 +28,7 @@ using namespace mi_interp1;
 #ifndef TAU
 #define TAU 256          // slot length in 100 MHz ticks (256 = 2.56 us)
 #endif
+__device__ unsigned long long g_active_ticks;   // time inside the gather rounds proper (wave 0 of each gathering group), summed over the grid
 __device__ __forceinline__ void wait_slot(unsigned parity)
 {
     for (;;) {
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(kPipeThreads) void pipe2_kernel(G1Dev g, const doub
     // it+1 prepares it.  The two roles are separate code paths run in strict alternation by each group (group 0:
     // prepare, gather, prepare, ...; group 1: gather, prepare, gather, ...), so that the register allocator sees that
     // the 64 registers of a tile's queries are dead while its owner gathers.
+    unsigned active_ticks = 0;
     auto gather_step = [&](long it) {        // this group owns tile `it` (it = -1: nothing yet, barriers only)
         const bool act = it >= 0;
         // regions are swept up, down, up, ...: L2 still holds the turn-around half.  Lane j of round u handles sorted
@@ -106,7 +108,9 @@ __global__ __launch_bounds__(kPipeThreads) void pipe2_kernel(G1Dev g, const doub
             for (int iv = 0; iv < 4; ++iv) { // eight rounds; the other group prepares its tile meanwhile
                 if (VARIANT == 2) wait_slot((blockIdx.x >> 3) & 1u);
                 if (VARIANT == 3) wait_slot(0u);
+                const unsigned ta_ = (unsigned)wall_clock64();
                 pipe_gather_rounds<MODE, FORMULA>(g, sq, first, stride, extrap);
+                if (VARIANT >= 2 && __builtin_amdgcn_readfirstlane((int)(threadIdx.x & 511)) == 0) active_ticks += (unsigned)wall_clock64() - ta_;
                 first += 8 * stride;
             }
         }
@@ -215,6 +219,7 @@ __global__ __launch_bounds__(kPipeThreads) void pipe2_kernel(G1Dev g, const doub
             if (++it >= nloc) break;
         }
     }
+    if (VARIANT >= 2 && (threadIdx.x & 511) == 0) atomicAdd(&g_active_ticks, (unsigned long long)active_ticks);
     if (tail && last_wg && grp == 0) {       // ragged tail (< one tile), four queries per lane at a time
         const double* tq = xq + ntiles * kSweepTile;
         double* to = yq + ntiles * kSweepTile;
@@ -281,12 +286,20 @@ int main(int argc, char** argv)
         printf("%-58s %.4f ms (min %.4f, max %.4f)  %.1f %% of 8 TB/s\n", name, ts[3], ts[0], ts[6], (16.0 * nq + 8e6) / (ts[3] * 1e-3) / 8e12 * 100);
         return ts[3];
     };
-    time("VARIANT 2: quarter-rounds in alternating time slots (two halves of each XCD)", [&] {
-        hipLaunchKernelGGL((pipe2_kernel<0, 3, 2>), dim3(256), dim3(kPipeThreads), 0, 0, g, xq, yb, ntiles, __builtin_nan(""), bscale, flag, (size_t)0, ProbeArgs{});
-    });
-    time("VARIANT 3: quarter-rounds in the even slots only, every CU (control)", [&] {
-        hipLaunchKernelGGL((pipe2_kernel<0, 3, 3>), dim3(256), dim3(kPipeThreads), 0, 0, g, xq, yb, ntiles, __builtin_nan(""), bscale, flag, (size_t)0, ProbeArgs{});
-    });
+    auto active = [&](const char* name, auto launch) {     // time inside the gather rounds, per tile
+        unsigned long long z = 0, v = 0;
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_active_ticks), &z, 8));
+        launch();
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_active_ticks), 8));
+        printf("    %s: %.2f us per tile inside the gather rounds (the four quarters, waits excluded)\n", name, (double)v * 0.01 / (double)ntiles);
+    };
+    auto v2 = [&] { hipLaunchKernelGGL((pipe2_kernel<0, 3, 2>), dim3(256), dim3(kPipeThreads), 0, 0, g, xq, yb, ntiles, __builtin_nan(""), bscale, flag, (size_t)0, ProbeArgs{}); };
+    auto v3 = [&] { hipLaunchKernelGGL((pipe2_kernel<0, 3, 3>), dim3(256), dim3(kPipeThreads), 0, 0, g, xq, yb, ntiles, __builtin_nan(""), bscale, flag, (size_t)0, ProbeArgs{}); };
+    time("VARIANT 2: quarter-rounds in alternating time slots (two halves of each XCD)", v2);
+    active("VARIANT 2", v2);
+    time("VARIANT 3: quarter-rounds in the even slots only, every CU (control)", v3);
+    active("VARIANT 3", v3);
     printf("TAU = %d ticks = %.2f us\n", TAU, TAU * 0.01);
     float t[2][2];
     for (int rep = 0; rep < 2; ++rep) {     // alternate the two forms: box-to-box and run-to-run drift is a few per cent

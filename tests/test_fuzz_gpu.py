@@ -24,7 +24,8 @@ def test_interp1_fuzz_short(mi_ctx):
 
 
 def test_interp2_fuzz_short(mi_ctx):
-    assert _load("gpu_fuzz_interp2").run(6.0, 2024, ctx=mi_ctx)["cases"] >= 100
+    res = _load("gpu_fuzz_interp2").run(8.0, 2024, ctx=mi_ctx)
+    assert res["cases"] >= 100 and res["ordered"] >= 10
 
 
 def test_edm_fuzz_short(mi_ctx, monkeypatch):
