@@ -211,6 +211,8 @@ mi_status reserve_workspace(mi_ctx* ctx, mi_grid2* g, size_t max_queries)
         g->ws_queries = 0;
     }
     if (max_queries == 0 || g->ord_nbx == 0) return MI_OK;
+    // positions inside the workspace are 32-bit: at most 2^31 queries per pass (56 GB); a longer call runs several passes
+    max_queries = std::min<size_t>(max_queries, (size_t)1 << 31);
     const size_t tiles = (max_queries + kOrdTile - 1) / kOrdTile;
     const size_t cap = tiles * kOrdTile;
     const size_t stride = (tiles + 63) & ~(size_t)63;
