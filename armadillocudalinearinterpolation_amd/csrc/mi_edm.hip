@@ -296,7 +296,8 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             asm volatile("" : "+v"(e2u), "+v"(e3u));
 #endif
             MI_EV_STAMP(1)
-#pragma unroll (HETERO ? 4 : MI_EVOLVE_UNROLL)
+            constexpr int kStateUnroll = HETERO ? 4 : MI_EVOLVE_UNROLL;
+#pragma unroll kStateUnroll
             for (unsigned k = 0; k < npl; ++k) {
                 if ((skip >> k) & 1u) continue;          // all-NaN slice: nothing to advance
                 const unsigned i = k * 64u + lane;

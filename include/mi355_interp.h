@@ -43,6 +43,8 @@
 extern "C" {
 #endif
 
+/* 3 (round 3): + mi_group_rccl_ranks, mi_ctx_set_interp2_path, mi_grid2_reserve, mi_grid2_info;
+ *              - mi_debug_sweep_timing (the sweep's phase stamps live in scripts/ harnesses now) */
 #define MI355_INTERP_ABI_VERSION 3
 
 typedef int mi_status;
