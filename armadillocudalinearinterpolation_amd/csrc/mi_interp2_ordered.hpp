@@ -20,12 +20,17 @@
 //
 // MEASURED (round 3, 1e8 queries, 4096^2 quad-cell table; profiles/r03_config3_ordered_*): fabric traffic 9.55 GB per call
 // (pass 1: 1.60 GB read + 2.05 GB written, pass 2: 2.90 + 1.22, pass 3: 1.00 + 0.80) against 15.1 GB for the direct
-// kernel -- and 2.55 ms against 2.06 ms: pass 1 0.64 ms, pass 2 1.60 ms, pass 3 0.31 ms.  Pass 2 is not bound by memory
-// (102 M of its 138 M L2 requests hit, 83 G requests/s against the 290 G/s the L2s sustain) but by the fp64 arithmetic of
-// eval2 -- two IEEE divisions, the bracket checks and the blend: 4.5e8 vector wave-instructions per call, ~290 per query,
-// 0.74 ms at the issue peak of the chip -- which the direct kernel hides under its 2 ms of line fetches.  So the ordered
-// path is NOT what mi_interp2_f64_dev takes by default (MI_INTERP2_ORDERED selects it); it stays as a tested alternative
-// with bit-identical results.
+// kernel -- and 2.55 ms against 2.06 ms: pass 1 0.64 ms, pass 2 1.60 ms, pass 3 0.31 ms.  Pass 2 is bound neither by
+// memory bandwidth (102 M of its 138 M L2 requests hit; 83 G requests/s) nor by arithmetic (moving both fp64 divisions
+// into pass 1 halved its vector-ALU work, 4.5e8 -> 2.0e8 wave-instructions, and left it at 1.75-2.05 ms with 45 % of the
+// wave cycles waiting) nor by the queue atomics (eight items per atomic: 1.77 ms) nor by memory-channel camping (a tile
+// pitch that is not a power of two: 1.75 ms): it is bound by the CU's vector memory path, which takes about one lane-request
+// per ns per CU when the requests are not coalesced into long runs.  A query costs pass 2 four
+// lane-requests -- its (x, y) record, the two 16-B halves of its cell, its result (five with weights + cell code records) --
+// = 4e8 / (256 CUs x 1.05 per ns) = 1.5 ms; phase stamps show the 1024 record loads of a work item taking 7-25 us and its
+// cell loads (L2 hits) 4-16 us behind the requests of the CU's other workgroups.  The direct kernel issues 3.5 lane-requests
+// per query (1.3 ms) and hides them under its 2 ms of line fetches.  So the ordered path is NOT what mi_interp2_f64_dev
+// takes by default (MI_INTERP2_ORDERED selects it); it stays as a tested alternative with bit-identical results.
 #pragma once
 #include "mi_common.hpp"
 

@@ -94,9 +94,9 @@ mi_status mi_ctx_set_query_order(mi_ctx* ctx, int order);
  * per query).  ORDERED: the call-wide cell ordering -- three passes through the grid's workspace (mi_grid2_reserve) that
  * order the queries of the whole call by table block, so that every block is fetched into one XCD's L2 once -- from one
  * tile (4096 queries) up, wherever the grid has a workspace.  It moves 9.6 GB instead of 15.1 GB per 1e8 queries on the
- * 4096^2 table and is nevertheless SLOWER on MI355X (2.55 ms against 2.06 ms: its block pass is bound by the fp64
- * arithmetic of the blend, which the direct kernel hides under its memory time), so AUTO does not
- * take it; it stays as a tested, bit-identical alternative.  Results are bit-identical on every path. */
+ * 4096^2 table and is nevertheless SLOWER on MI355X (2.55 ms against 2.06 ms: its block pass issues four poorly
+ * coalesced vector-memory requests per query and a CU takes about one such request per ns), so AUTO
+ * does not take it; it stays as a tested, bit-identical alternative.  Results are bit-identical on every path. */
 #define MI_INTERP2_AUTO    0
 #define MI_INTERP2_DIRECT  1
 #define MI_INTERP2_ORDERED 2
