@@ -11,6 +11,12 @@
 // CUs gather at any moment, do they gather twice as fast (the L2 request rate being what bounds the rounds), so that the
 // other half of the time is free for the streams?  VARIANT 3: same slots, every workgroup parity 0 (control: all gather
 // in the even slots and nobody in the odd ones).
+//
+// VARIANT 4 (time slots + deferred burst): as 2, and the group that has gathered does NOT issue its stores and next loads
+// between the tiles: it keeps the results in registers through barrier C and issues the stores in the first slot of the other
+// parity of its next (prepare) step and the loads of its next tile in the following such slot -- slots in which the other
+// half of the XCD's CUs gather and this CU's own vector memory path is idle.  Then a tile costs eight slots plus the
+// read-back and the scatter, and the bursts of one half of the XCD fall into the rounds of the other.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I armadillocudalinearinterpolation_amd/csrc \
 //         -o scripts/exp_pipe2 scripts/exp_pipe2.hip
 #include <hip/hip_runtime.h>
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(kPipeThreads) void pipe2_kernel(G1Dev g, const doub
         }
     };
     for (int b = threadIdx.x; b < 2 * kSweepBins; b += kPipeThreads) (&hist[0][0])[b] = 0;
-    if (grp == 0 && nloc > 0) load_tile(0);
+    if (VARIANT != 4 && grp == 0 && nloc > 0) load_tile(0);
     pipe_barrier();
     unsigned* const myhist = hist[grp];
     // barrier among the 8 waves of this group only: a monotonic arrival counter in LDS
@@ -96,6 +102,7 @@ __global__ __launch_bounds__(kPipeThreads) void pipe2_kernel(G1Dev g, const doub
     // prepare, gather, prepare, ...; group 1: gather, prepare, gather, ...), so that the register allocator sees that
     // the 64 registers of a tile's queries are dead while its owner gathers.
     unsigned active_ticks = 0;
+    long pending = -1;                       // VARIANT 4: tile whose results sit in q, not yet stored
     auto gather_step = [&](long it) {        // this group owns tile `it` (it = -1: nothing yet, barriers only)
         const bool act = it >= 0;
         // regions are swept up, down, up, ...: L2 still holds the turn-around half.  Lane j of round u handles sorted
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(kPipeThreads) void pipe2_kernel(G1Dev g, const doub
         if (act) {
 #pragma unroll 1
             for (int iv = 0; iv < 4; ++iv) { // eight rounds; the other group prepares its tile meanwhile
-                if (VARIANT == 2) wait_slot((blockIdx.x >> 3) & 1u);
+                if (VARIANT == 2 || VARIANT == 4) wait_slot((blockIdx.x >> 3) & 1u);
                 if (VARIANT == 3) wait_slot(0u);
                 const unsigned ta_ = (unsigned)wall_clock64();
                 pipe_gather_rounds<MODE, FORMULA>(g, sq, first, stride, extrap);
@@ -127,6 +134,11 @@ __global__ __launch_bounds__(kPipeThreads) void pipe2_kernel(G1Dev g, const doub
             for (int u = 0; u < kSweepK; ++u) q[u] = 0.0;   // explicit definition on every path: q is dead during the rounds
         }
         pipe_barrier();
+        if (VARIANT == 4) {                  // results stay in q; stored at the start of this group's next prepare step
+            pending = act ? it : -1;
+            pipe_barrier();
+            return;
+        }
         if (act) store_tile(it);             // results to HBM; nothing waited for
         // Stores and loads are issued HERE, while nobody gathers (the other group scatters into LDS): measured against
         // leaving the last quarter / eighth of the loads (0.682 / 0.671 ms vs 0.672 ms) or all stores and loads (0.712 vs
@@ -147,6 +159,11 @@ __global__ __launch_bounds__(kPipeThreads) void pipe2_kernel(G1Dev g, const doub
         unsigned rank2[kSweepK / 2];         // rank inside the region (histogram ticket), two per register
 #pragma unroll
         for (int u = 0; u < kSweepK / 2; ++u) rank2[u] = 0;
+        if (VARIANT == 4) {
+            const unsigned par = (blockIdx.x >> 3) & 1u;
+            if (pending >= 0) { wait_slot(1u - par); store_tile(pending); pending = -1; wait_slot(par); }
+            if (act) { wait_slot(1u - par); load_tile(it + 1); }
+        }
         if (act) {
             // region histogram (own histogram, cleared in the previous step)
 #pragma unroll
@@ -219,6 +236,7 @@ __global__ __launch_bounds__(kPipeThreads) void pipe2_kernel(G1Dev g, const doub
             if (++it >= nloc) break;
         }
     }
+    if (VARIANT == 4 && pending >= 0) store_tile(pending);
     if (VARIANT >= 2 && (threadIdx.x & 511) == 0) atomicAdd(&g_active_ticks, (unsigned long long)active_ticks);
     if (tail && last_wg && grp == 0) {       // ragged tail (< one tile), four queries per lane at a time
         const double* tq = xq + ntiles * kSweepTile;
@@ -298,6 +316,9 @@ int main(int argc, char** argv)
     auto v3 = [&] { hipLaunchKernelGGL((pipe2_kernel<0, 3, 3>), dim3(256), dim3(kPipeThreads), 0, 0, g, xq, yb, ntiles, __builtin_nan(""), bscale, flag, (size_t)0, ProbeArgs{}); };
     time("VARIANT 2: quarter-rounds in alternating time slots (two halves of each XCD)", v2);
     active("VARIANT 2", v2);
+    auto v4 = [&] { hipLaunchKernelGGL((pipe2_kernel<0, 3, 4>), dim3(256), dim3(kPipeThreads), 0, 0, g, xq, yb, ntiles, __builtin_nan(""), bscale, flag, (size_t)0, ProbeArgs{}); };
+    time("VARIANT 4: time slots + stores / loads deferred into the other half's slots", v4);
+    active("VARIANT 4", v4);
     time("VARIANT 3: quarter-rounds in the even slots only, every CU (control)", v3);
     active("VARIANT 3", v3);
     printf("TAU = %d ticks = %.2f us\n", TAU, TAU * 0.01);
