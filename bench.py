@@ -434,6 +434,9 @@ def main():
         result["roofline"]["l2_request_bound_ms"] = l2["l2_request_bound_ms"]
         result["roofline"]["l2_request_frac"] = l2["l2_request_bound_ms"] / (kernel_s * 1e3)
         result["roofline"]["l2_requests_per_launch"] = l2["tcc_req_per_launch"]
+        # the same requests at the rate the XCDs' vector request paths were MEASURED to sustain (33 per ns per XCD with all CUs
+        # gathering from an L2-resident table, profiles/r03_exp_gather_rate_vs_active_cus.log): the floor of this algorithm
+        result["roofline"]["request_floor_ms_at_measured_cap"] = l2["tcc_req_per_launch"] / (8 * 33.0e9) * 1e3
         result["roofline"]["l2_note"] = ("TCC_REQ per launch / (128 L2 channels x %.2f GHz measured clock): the time the XCD L2s need "
                                          "for the launch's requests at one per channel-clock; profiled TCC_BUSY fraction %.2f"
                                          % (l2["gpu_clock_hz"] * 1e-9, l2.get("tcc_busy_frac") or float("nan")))
