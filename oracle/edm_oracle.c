@@ -25,7 +25,16 @@
  *   - exp/log/pow are the software routines in this file (Cephes-style
  *     polynomials, <= ~1 ulp), not libm;
  *   - the decisions where the reference is undefined or racy are listed in
- *     DESIGN.md "EventDrivenMap: documented decisions" and marked [D1]..[D7].
+ *     DESIGN.md "EventDrivenMap: documented decisions" and marked [D1]..[D8];
+ *     orc_edm_compute_f_counted counts how often an evaluation reaches one of
+ *     them (tests/test_edm_oracle_cpu.py: never, on the BASELINE inputs).
+ * Two SENSITIVITY builds of this same file exist for tests only (oracle/Makefile):
+ * liboracle_contract.so (-ffp-contract=fast -mfma: the compiler fuses a*b+c as
+ * nvcc -fmad=true would, reference Makefile:3) and liboracle_libm.so
+ * (-DORC_EDM_LIBM_MATH: libm expf/logf/powf instead of the routines below, a
+ * stand-in for "some other <= 2 ulp implementation" such as CUDA's libdevice).
+ * They bound how far the unreproducible parts of the reference's arithmetic can
+ * move f; they are never what the HIP path is compared with.
  */
 #include <math.h>
 #include <stddef.h>
@@ -54,6 +63,30 @@ typedef struct orc_edm_params {
 #define ORC_MAX_SPIKES 8
 #define ORC_MAX_GRID 1024
 
+/* Optional decision-coverage counters (tests/test_edm_oracle_cpu.py): how often an evaluation reaches one of the points
+ * where this restatement cannot follow the reference ([D0], [D1], [D2], [D5], [D8] of DESIGN.md) -- so that a test can
+ * state that none of them is exercised on the BASELINE inputs -- plus plain workload counts.  All fields are totals over
+ * the realisations of one orc_edm_compute_f_counted call, except the two maxima. */
+typedef struct orc_edm_counters {
+    uint64_t realisations, accepted, events;
+    uint64_t argmin_ties;            /* [D1] events whose minimal firing time (a real one, < "never") is shared by >= 2 neurons */
+    uint64_t no_firing_events;       /* [D1] events whose minimal time is the "never" value 100 (no neuron will fire)          */
+    uint64_t nan_times;              /* [D1] candidate firing times that were NaN                                                */
+    uint64_t argmin_tree_mismatch;   /* [D1] events at which the LITERAL reference reduction (orc_edm_argmin_reference_tree:
+                                      *      32-wide shuffle tree + padded second stage, :843-881) picks another (time, index)
+                                      *      than this file's rule; counted only when n_grid is a multiple of 32             */
+    uint64_t unwritten_last_slots;   /* [D2] bumps of ACCEPTED realisations that never recorded a pre-T event (t0/i0 unset)   */
+    uint64_t unwritten_last_slots_all; /*    the same over all realisations                                                     */
+    uint64_t seed_scans_empty;       /* [D5] seed scans (one per bump m >= 1) that found no grid point                          */
+    uint64_t newton_cap_hits;        /* [D0] firing-time solves that stopped at newton_max_iter                                 */
+    uint64_t event_cap_hits;         /* [D8] realisations that left the event loop at max_events                                */
+    uint64_t time_cap_exits;         /*      realisations that left it at t >= 2T without every bump crossing (:601)          */
+    uint64_t newton_solves, newton_iters;
+    uint64_t wave64_rounds;          /* sum over events of max over l of #{firing neurons i : i mod 64 == l} (the HIP kernel's rounds) */
+    uint32_t max_newton_iter;        /* largest iteration count of any solve                                                    */
+    uint32_t max_events_one;         /* largest event count of any realisation                                                  */
+} orc_edm_counters;
+
 void orc_restrict_f32(const float* t0, const uint16_t* i0, const float* t1, const uint16_t* i1,
                       float T, float L, uint32_t ngrid, float* out, size_t n);
 void orc_masked_mean_f32(const float* x, const uint32_t* accept, size_t nreal, size_t nspikes,
@@ -65,6 +98,9 @@ void orc_masked_mean_f32(const float* x, const uint32_t* accept, size_t nreal, s
  * in r for (exp(r)-1-r)/r^2; scale with ldexpf. */
 float orc_edm_expf(float x)
 {
+#ifdef ORC_EDM_LIBM_MATH   /* sensitivity probe only (oracle/Makefile: liboracle_libm.so), never the parity oracle */
+    return expf(x);
+#endif
     if (x != x) return x;
     if (x > 88.72283935546875f) return INFINITY;
     if (x < -103.97208404541015625f) return 0.0f;
@@ -86,6 +122,9 @@ float orc_edm_expf(float x)
 /* log(x): x = m*2^e with m in [sqrt(1/2), sqrt(2)); degree-8 polynomial in m-1. */
 float orc_edm_logf(float x)
 {
+#ifdef ORC_EDM_LIBM_MATH
+    return logf(x);
+#endif
     if (x != x) return x;
     if (x < 0.0f) return NAN;
     if (x == 0.0f) return -INFINITY;
@@ -115,7 +154,13 @@ float orc_edm_logf(float x)
 
 /* pow(a, b) for the firing test (a = s/(vth-I), b = 1/beta): exp(b*log(a)).
  * a < 0 -> NaN (as C pow for non-integer b), a == 0 -> exp(-inf*b). */
-float orc_edm_powf(float a, float b) { return orc_edm_expf(b * orc_edm_logf(a)); }
+float orc_edm_powf(float a, float b)
+{
+#ifdef ORC_EDM_LIBM_MATH
+    return powf(a, b);      /* the reference calls pow() itself (:559), not exp(b log a) */
+#endif
+    return orc_edm_expf(b * orc_edm_logf(a));
+}
 
 /* ---- per-neuron parameter heterogeneity ----------------------------------
  * The reference draws beta[r][i] ~ N(p0, sigma) with cuRAND XORWOW seeded from
@@ -192,17 +237,21 @@ void orc_edm_coupling(const orc_edm_params* P, float* w)
  * [D5] When no point qualifies the reference leaves the entry stale (whatever
  * the previous call, or malloc, left there); here `ind` is in/out so the caller
  * carries the previous value, initially 0. */
-void orc_edm_seed_indices(const orc_edm_params* P, const double* Z, uint16_t* ind)
+static void seed_indices_impl(const orc_edm_params* P, const double* Z, uint16_t* ind, orc_edm_counters* C)
 {
     const uint32_t N = P->n_grid, S = P->n_spikes;
     ind[0] = (uint16_t)(N / 2);
     for (uint32_t m = 1; m < S; ++m) {
+        int found = 0;
         for (uint32_t i = ind[m - 1]; i > 0; --i) {
             const float xi = -P->L + ((float)(2u * i) * P->L) / (float)N;
-            if ((double)xi < -Z[0] * Z[m]) { ind[m] = (uint16_t)i; break; }
+            if ((double)xi < -Z[0] * Z[m]) { ind[m] = (uint16_t)i; found = 1; break; }
         }
+        if (C && !found) C->seed_scans_empty += 1;
     }
 }
+
+void orc_edm_seed_indices(const orc_edm_params* P, const double* Z, uint16_t* ind) { seed_indices_impl(P, Z, ind, NULL); }
 
 /* ---- LiftKernel (EventDrivenMap.cu:505-542) ----------------------------------
  * U = (c, 0, Z1, .., Z_{S-1}) in fp32.  Abscissa descends: x = L - (2L/N)*i.
@@ -288,7 +337,8 @@ static inline orc_fdf orc_fun_dfun(const orc_edm_params* P, float t, float v, fl
     return r;
 }
 
-float orc_edm_event_time(const orc_edm_params* P, float v0, float s0, float beta)
+/* iters (optional): number of Newton iterations taken; -1 when the neuron will never fire (decision false) */
+static float event_time_impl(const orc_edm_params* P, float v0, float s0, float beta, int* iters)
 {
     const float gap = P->vth - P->I;
     const float ratio = s0 / gap;
@@ -307,7 +357,55 @@ float orc_edm_event_time(const orc_edm_params* P, float v0, float s0, float beta
         df = r.df;
         ++counter;
     }
+    if (iters) *iters = decision ? (int)counter : -1;
     return fabsf(t) + 100.0f * (1.0f - (float)decision);
+}
+
+float orc_edm_event_time(const orc_edm_params* P, float v0, float s0, float beta) { return event_time_impl(P, v0, s0, beta, NULL); }
+
+/* ---- blockReduceMin / warpReduceMin, literally (EventDrivenMap.cu:843-881) ----
+ * What the reference's own reduction returns on a 32-wide-warp machine for a block of n = blockDim.x threads holding
+ * (time[i], index i): `__shfl_down` trees in which a lane keeps its own pair only when its time is strictly smaller
+ * (:849-850; on a tie the HIGHER lane's index moves down, a NaN coming from above displaces a number, a NaN already held
+ * is displaced by anything), then a second tree over the per-warp results padded with (100.0f, 0) in the lanes
+ * >= n/32 (:867-868).  `__shfl_down` past the end of the warp returns the lane's own value.  Only meaningful for
+ * n a multiple of 32 (the reference launches 1024 or 512 threads); used by the decision-coverage counters, not by the
+ * oracle's own event loop (see [D1]). */
+static void warp_reduce_min_literal(float* t, uint32_t* ix)
+{
+    for (int offset = 16; offset > 0; offset /= 2) {
+        float nt[32];
+        uint32_t ni[32];
+        for (int l = 0; l < 32; ++l) {
+            const int src = (l + offset < 32) ? l + offset : l;
+            const float dummy_t = t[src];
+            const uint32_t dummy_i = ix[src];
+            const float vt = (t[l] < dummy_t) ? t[l] : dummy_t;      /* :849 */
+            nt[l] = vt;
+            ni[l] = (vt < dummy_t) ? ix[l] : dummy_i;                /* :850, tested AFTER the update of val.time */
+        }
+        memcpy(t, nt, sizeof(nt));
+        memcpy(ix, ni, sizeof(ni));
+    }
+}
+
+void orc_edm_argmin_reference_tree(const float* time, uint32_t n, float* best, uint32_t* index)
+{
+    float st[32];
+    uint32_t si[32];
+    const uint32_t nwarps = n / 32u;                                 /* blockDim.x / warpSize, :866 */
+    for (uint32_t l = 0; l < 32u; ++l) { st[l] = 100.0f; si[l] = 0u; }   /* :867-868 */
+    for (uint32_t w = 0; w < nwarps && w < 32u; ++w) {
+        float t[32];
+        uint32_t ix[32];
+        for (uint32_t l = 0; l < 32u; ++l) { t[l] = time[w * 32u + l]; ix[l] = w * 32u + l; }
+        warp_reduce_min_literal(t, ix);
+        st[w] = t[0];
+        si[w] = ix[0];
+    }
+    warp_reduce_min_literal(st, si);
+    *best = st[0];
+    *index = si[0];
 }
 
 /* ---- EvolveKernel for one realisation (EventDrivenMap.cu:575-674) -----------
@@ -319,10 +417,10 @@ float orc_edm_event_time(const orc_edm_params* P, float v0, float s0, float beta
  * [D3] the bump-assignment rule `minIndex += (d_i < d_minIndex)` (:625-629) is
  *      reproduced as written (it is not a true arg-min for S >= 3).
  */
-void orc_edm_evolve_one(const orc_edm_params* P, const float* v0, const float* s0, const float* w,
-                        const uint16_t* seed_ind, uint32_t r,
-                        float* last_t, uint16_t* last_i, float* cross_t, uint16_t* cross_i,
-                        uint32_t* accept, uint32_t* n_events)
+static void evolve_one_impl(const orc_edm_params* P, const float* v0, const float* s0, const float* w,
+                            const uint16_t* seed_ind, uint32_t r,
+                            float* last_t, uint16_t* last_i, float* cross_t, uint16_t* cross_i,
+                            uint32_t* accept, uint32_t* n_events, orc_edm_counters* C)
 {
     const uint32_t N = P->n_grid, S = P->n_spikes;
     const float T = P->time_horizon;
@@ -332,15 +430,45 @@ void orc_edm_evolve_one(const orc_edm_params* P, const float* v0, const float* s
     float lt[ORC_MAX_SPIKES], ct[ORC_MAX_SPIKES];
     for (uint32_t m = 0; m < S; ++m) { li[m] = seed_ind[m]; ci[m] = 0; lt[m] = 0.0f; ct[m] = 0.0f; }
     const uint32_t full = (1u << S) - 1u;
-    uint32_t crossed = 0, events = 0;
+    uint32_t crossed = 0, events = 0, last_written = 0;
     float now = 0.0f;
     /* hard event cap (same rule as the HIP kernel): termination even when time cannot advance */
     while (crossed < full && now < 2.0f * T && events < P->max_events) {
         float best = INFINITY;
         uint32_t idx = 0;
+        uint32_t n_at_best = 0;
+        uint8_t per_lane[64] = {0};
+        float taus[ORC_MAX_GRID];
         for (uint32_t i = 0; i < N; ++i) {
-            const float tau = orc_edm_event_time(P, v[i], s[i], beta[i]);
+            int it = -1;
+            const float tau = event_time_impl(P, v[i], s[i], beta[i], C ? &it : NULL);
+            if (C) {
+                taus[i] = tau;
+                if (tau != tau) C->nan_times += 1;
+                if (it >= 0) {
+                    C->newton_solves += 1;
+                    C->newton_iters += (uint64_t)it;
+                    if ((uint32_t)it > C->max_newton_iter) C->max_newton_iter = (uint32_t)it;
+                    if ((uint32_t)it >= P->newton_max_iter) C->newton_cap_hits += 1;
+                    per_lane[i & 63u] += 1;
+                }
+                if (tau == best) n_at_best += 1;
+                else if (tau < best) n_at_best = 1;
+            }
             if (tau < best) { best = tau; idx = i; }
+        }
+        if (C) {
+            if (best >= 100.0f) C->no_firing_events += 1;
+            else if (n_at_best > 1) C->argmin_ties += 1;
+            if (N % 32u == 0u) {
+                float tb;
+                uint32_t ti;
+                orc_edm_argmin_reference_tree(taus, N, &tb, &ti);
+                if (!(tb == best) || ti != idx) C->argmin_tree_mismatch += 1;
+            }
+            uint8_t rounds = 0;
+            for (int l = 0; l < 64; ++l) if (per_lane[l] > rounds) rounds = per_lane[l];
+            C->wave64_rounds += rounds;
         }
         const float dt = best;
         const float e1 = orc_edm_expf(-dt);
@@ -365,12 +493,33 @@ void orc_edm_evolve_one(const orc_edm_params* P, const float* v0, const float* s
         }
         if (!(crossed & (1u << mi))) {
             if (now > T) { ct[mi] = now; ci[mi] = (uint16_t)idx; crossed += (1u << mi); }
-            else { lt[mi] = now; li[mi] = (uint16_t)idx; }
+            else { lt[mi] = now; li[mi] = (uint16_t)idx; last_written |= (1u << mi); }
         }
     }
     for (uint32_t m = 0; m < S; ++m) { last_t[m] = lt[m]; last_i[m] = li[m]; cross_t[m] = ct[m]; cross_i[m] = ci[m]; }
     *accept = (crossed == full) ? 1u : 0u;
     if (n_events) *n_events = events;
+    if (C) {
+        C->realisations += 1;
+        C->accepted += *accept;
+        C->events += events;
+        if (events > C->max_events_one) C->max_events_one = events;
+        const uint32_t unwritten = (uint32_t)__builtin_popcount(full & ~last_written);
+        C->unwritten_last_slots_all += unwritten;
+        if (*accept) C->unwritten_last_slots += unwritten;
+        if (crossed < full) {
+            if (events >= P->max_events) C->event_cap_hits += 1;
+            else C->time_cap_exits += 1;
+        }
+    }
+}
+
+void orc_edm_evolve_one(const orc_edm_params* P, const float* v0, const float* s0, const float* w,
+                        const uint16_t* seed_ind, uint32_t r,
+                        float* last_t, uint16_t* last_i, float* cross_t, uint16_t* cross_i,
+                        uint32_t* accept, uint32_t* n_events)
+{
+    evolve_one_impl(P, v0, s0, w, seed_ind, r, last_t, last_i, cross_t, cross_i, accept, n_events, NULL);
 }
 
 /* ---- ComputeF (EventDrivenMap.cu:154-240) --------------------------------------
@@ -380,9 +529,23 @@ void orc_edm_evolve_one(const orc_edm_params* P, const float* v0, const float* s
  * the accepted-realisation sums (fp64, index order) and the count.
  * [D4] accepted-realisation mean: interp_oracle.c orc_masked_mean_f32.
  */
-int orc_edm_compute_f(const orc_edm_params* P, const double* Z, double* f, uint16_t* seed_ind,
-                      float* dv, float* ds, float* dw, float* dt0, uint16_t* di0, float* dt1,
-                      uint16_t* di1, uint32_t* daccept, float* drestricted, double* dsums, int nthreads)
+static void counters_add(orc_edm_counters* a, const orc_edm_counters* b)
+{
+    a->realisations += b->realisations; a->accepted += b->accepted; a->events += b->events;
+    a->argmin_ties += b->argmin_ties; a->no_firing_events += b->no_firing_events; a->nan_times += b->nan_times;
+    a->argmin_tree_mismatch += b->argmin_tree_mismatch;
+    a->unwritten_last_slots += b->unwritten_last_slots; a->unwritten_last_slots_all += b->unwritten_last_slots_all;
+    a->seed_scans_empty += b->seed_scans_empty; a->newton_cap_hits += b->newton_cap_hits;
+    a->event_cap_hits += b->event_cap_hits; a->time_cap_exits += b->time_cap_exits;
+    a->newton_solves += b->newton_solves; a->newton_iters += b->newton_iters; a->wave64_rounds += b->wave64_rounds;
+    if (b->max_newton_iter > a->max_newton_iter) a->max_newton_iter = b->max_newton_iter;
+    if (b->max_events_one > a->max_events_one) a->max_events_one = b->max_events_one;
+}
+
+static int compute_f_impl(const orc_edm_params* P, const double* Z, double* f, uint16_t* seed_ind,
+                          float* dv, float* ds, float* dw, float* dt0, uint16_t* di0, float* dt1,
+                          uint16_t* di1, uint32_t* daccept, float* drestricted, double* dsums, int nthreads,
+                          orc_edm_counters* C)
 {
     const uint32_t N = P->n_grid, S = P->n_spikes, R = P->n_real;
     if (N < 2 || N > ORC_MAX_GRID || S < 1 || S > ORC_MAX_SPIKES || R < 1) return 1;
@@ -391,7 +554,7 @@ int orc_edm_compute_f(const orc_edm_params* P, const double* Z, double* f, uint1
     U0[0] = Z[0]; U0[1] = 0.0;
     for (uint32_t i = 2; i <= S; ++i) U0[i] = Z[i - 1];
     for (uint32_t i = 0; i <= S; ++i) U[i] = (float)U0[i];
-    orc_edm_seed_indices(P, Z, seed_ind);
+    seed_indices_impl(P, Z, seed_ind, C);
 
     float* v = (float*)malloc(sizeof(float) * N);
     float* s = (float*)malloc(sizeof(float) * N);
@@ -411,12 +574,18 @@ int orc_edm_compute_f(const orc_edm_params* P, const double* Z, double* f, uint1
         float lt[ORC_MAX_SPIKES], ct[ORC_MAX_SPIKES];
         uint16_t li[ORC_MAX_SPIKES], ci[ORC_MAX_SPIKES];
         uint32_t a;
-        orc_edm_evolve_one(P, v, s, w, seed_ind, (uint32_t)r, lt, li, ct, ci, &a, NULL);
+        orc_edm_counters local;
+        memset(&local, 0, sizeof(local));
+        evolve_one_impl(P, v, s, w, seed_ind, (uint32_t)r, lt, li, ct, ci, &a, NULL, C ? &local : NULL);
         for (uint32_t m = 0; m < S; ++m) {
             const size_t k = (size_t)m * R + (size_t)r;     /* [spike][realisation], :661-668 */
             t0[k] = lt[m]; i0[k] = li[m]; t1[k] = ct[m]; i1[k] = ci[m];
         }
         acc[r] = a;
+        if (C) {
+#pragma omp critical(orc_edm_counters_merge)
+            counters_add(C, &local);
+        }
     }
     orc_restrict_f32(t0, i0, t1, i1, P->time_horizon, P->L, N, xr, SR);
     float mean[ORC_MAX_SPIKES];
@@ -455,6 +624,22 @@ int orc_edm_compute_f(const orc_edm_params* P, const double* Z, double* f, uint1
     if (drestricted) memcpy(drestricted, xr, sizeof(float) * SR);
     free(v); free(s); free(w); free(t0); free(t1); free(xr); free(i0); free(i1); free(acc);
     return 0;
+}
+
+int orc_edm_compute_f(const orc_edm_params* P, const double* Z, double* f, uint16_t* seed_ind,
+                      float* dv, float* ds, float* dw, float* dt0, uint16_t* di0, float* dt1,
+                      uint16_t* di1, uint32_t* daccept, float* drestricted, double* dsums, int nthreads)
+{
+    return compute_f_impl(P, Z, f, seed_ind, dv, ds, dw, dt0, di0, dt1, di1, daccept, drestricted, dsums, nthreads, NULL);
+}
+
+/* the same evaluation, also ADDING its decision-coverage counts to *C (the caller zeroes C before the first call) */
+int orc_edm_compute_f_counted(const orc_edm_params* P, const double* Z, double* f, uint16_t* seed_ind,
+                              float* dv, float* ds, float* dw, float* dt0, uint16_t* di0, float* dt1,
+                              uint16_t* di1, uint32_t* daccept, float* drestricted, double* dsums, int nthreads,
+                              orc_edm_counters* C)
+{
+    return compute_f_impl(P, Z, f, seed_ind, dv, ds, dw, dt0, di0, dt1, di1, daccept, drestricted, dsums, nthreads, C);
 }
 
 /* vectorised probes of the math routines (tests compare the GPU versions) */

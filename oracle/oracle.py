@@ -170,8 +170,34 @@ class EdmParams(C.Structure):
     ]
 
 
-def _edm_lib():
-    L = lib()
+class EdmCounters(C.Structure):
+    """orc_edm_counters: decision-coverage counts of orc_edm_compute_f_counted (see oracle/edm_oracle.c)."""
+    _fields_ = [(n, C.c_uint64) for n in (
+        "realisations", "accepted", "events", "argmin_ties", "no_firing_events", "nan_times", "argmin_tree_mismatch", "unwritten_last_slots",
+        "unwritten_last_slots_all", "seed_scans_empty", "newton_cap_hits", "event_cap_hits", "time_cap_exits",
+        "newton_solves", "newton_iters", "wave64_rounds")] + [("max_newton_iter", C.c_uint32), ("max_events_one", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+_variants = {}
+
+
+def _variant_lib(name):
+    """Test-only SENSITIVITY builds of the oracle sources (oracle/Makefile): 'contract' (-ffp-contract=fast -mfma) and
+    'libm' (libm expf/logf/powf).  Never the parity oracle."""
+    if name not in _variants:
+        path = os.path.join(_HERE, "liboracle_%s.so" % name)
+        srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")] + [os.path.join(_HERE, "Makefile")]
+        if not os.path.exists(path) or any(os.path.getmtime(path) < os.path.getmtime(s_) for s_ in srcs):
+            subprocess.check_call(["make", "-s", "-B", "-C", _HERE, os.path.basename(path)])
+        _variants[name] = C.CDLL(path)
+    return _variants[name]
+
+
+def _edm_lib(variant=None):
+    L = lib() if variant is None else _variant_lib(variant)
     if not getattr(L, "_edm_ready", False):
         pp = C.POINTER(EdmParams)
         vp = C.c_void_p
@@ -179,6 +205,8 @@ def _edm_lib():
         L.orc_edm_default_params.restype = None
         L.orc_edm_compute_f.argtypes = [pp, _f64p, _f64p, _u16p] + [vp] * 10 + [C.c_int]
         L.orc_edm_compute_f.restype = C.c_int
+        L.orc_edm_compute_f_counted.argtypes = [pp, _f64p, _f64p, _u16p] + [vp] * 10 + [C.c_int, C.POINTER(EdmCounters)]
+        L.orc_edm_compute_f_counted.restype = C.c_int
         L.orc_edm_math_probe.argtypes = [C.c_int, _f32p, _f32p, _f32p, C.c_size_t]
         L.orc_edm_math_probe.restype = None
         L.orc_edm_coupling.argtypes = [pp, _f32p]
@@ -193,6 +221,8 @@ def _edm_lib():
         L.orc_edm_beta.restype = C.c_float
         L.orc_edm_residual_from_sums.argtypes = [pp, _f64p, _f64p, _f64p]
         L.orc_edm_residual_from_sums.restype = None
+        L.orc_edm_argmin_reference_tree.argtypes = [_f32p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        L.orc_edm_argmin_reference_tree.restype = None
         L._edm_ready = True
     return L
 
@@ -240,6 +270,14 @@ def edm_beta(p, r, i):
     return float(_edm_lib().orc_edm_beta(C.byref(p), int(r), int(i)))
 
 
+def edm_argmin_reference_tree(times):
+    """The reference's blockReduceMin (EventDrivenMap.cu:843-881) emulated literally for 32-wide warps: (time, index)."""
+    times = np.ascontiguousarray(times, dtype=np.float32)
+    t, i = C.c_float(0), C.c_uint32(0)
+    _edm_lib().orc_edm_argmin_reference_tree(times, times.size, C.byref(t), C.byref(i))
+    return float(t.value), int(i.value)
+
+
 def edm_residual_from_sums(p, Z, sums):
     """f from the element-wise sum of the shards' partial blocks (2S+1 doubles)."""
     f = np.empty(p.n_spikes, dtype=np.float64)
@@ -247,8 +285,10 @@ def edm_residual_from_sums(p, Z, sums):
     return f
 
 
-def edm_compute_f(p, Z, seed_ind=None, nthreads=1, debug=True):
-    """Whole residual.  Returns (f, dbg) with dbg holding every stage output."""
+def edm_compute_f(p, Z, seed_ind=None, nthreads=1, debug=True, counters=None, variant=None):
+    """Whole residual.  Returns (f, dbg) with dbg holding every stage output.
+    counters: an EdmCounters that this evaluation's decision-coverage counts are ADDED to.
+    variant: None (the oracle) or 'contract' / 'libm' (sensitivity builds, tests only)."""
     Z = _c64(Z)
     S, R, N = p.n_spikes, p.n_real, p.n_grid
     f = np.empty(S, dtype=np.float64)
@@ -262,7 +302,11 @@ def edm_compute_f(p, Z, seed_ind=None, nthreads=1, debug=True):
     }
     order = ["v", "s", "w", "t0", "i0", "t1", "i1", "accept", "restricted", "sums"]
     ptrs = [C.c_void_p(dbg[k].ctypes.data) if debug else None for k in order]
-    rc = _edm_lib().orc_edm_compute_f(C.byref(p), Z, f, ind, *ptrs, int(nthreads))
+    L = _edm_lib(variant)
+    if counters is not None:
+        rc = L.orc_edm_compute_f_counted(C.byref(p), Z, f, ind, *ptrs, int(nthreads), C.byref(counters))
+    else:
+        rc = L.orc_edm_compute_f(C.byref(p), Z, f, ind, *ptrs, int(nthreads))
     if rc != 0:
         raise ValueError("orc_edm_compute_f failed (%d)" % rc)
     dbg["seed_ind"] = ind
