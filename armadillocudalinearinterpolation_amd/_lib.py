@@ -112,6 +112,7 @@ SIGNATURES = {
     "mi_edm_compute_f_end": (_i32, [_vp, _vp, _vp]),
     "mi_edm_residual_from_sums": (_i32, [C.POINTER(EdmParams), _vp, _vp, _vp]),
     "mi_edm_debug_read": (_i32, [_vp] + [_vp] * 10),
+    "mi_edm_debug_counters": (_i32, [_vp, C.POINTER(C.c_uint64 * 8)]),
     "mi_edm_last_timings": (_i32, [_vp, C.POINTER(_f32 * 4)]),
     "mi_edm_math_probe": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _sz]),
 }

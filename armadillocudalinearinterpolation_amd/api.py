@@ -494,6 +494,14 @@ class EventDrivenMap:
         check(self._L.mi_edm_debug_read(self._h, *[_ptr(out[k]) for k in order]), self._ctx._h)
         return out
 
+    def debug_counters(self):
+        """Decision-coverage taps of the last ComputeF (mi_edm_debug_counters: one more, tapped, evolve)."""
+        c = (C.c_uint64 * 8)()
+        check(self._L.mi_edm_debug_counters(self._h, C.byref(c)), self._ctx._h)
+        names = ("events", "max_events_one", "max_newton_iter", "newton_cap_hits", "event_cap_hits", "accepted",
+                 "no_firing_events", "argmin_ties")
+        return {n: int(c[i]) for i, n in enumerate(names)}
+
     def last_timings(self):
         ms = (C.c_float * 4)()
         check(self._L.mi_edm_last_timings(self._h, C.byref(ms)), self._ctx._h)

@@ -36,9 +36,6 @@ constexpr int kEvolveBlock = 256;   // 4 waves = 4 realisations per workgroup
 // kernel fires at ever shorter intervals).  Every wave must reach an exit, so the loop also stops after
 // max_events events (the realisation is then simply not accepted); the oracle applies the same rule.
 constexpr unsigned kMaxEventsLimit = 1u << 24;
-#ifndef MI_EVOLVE_UNROLL
-#define MI_EVOLVE_UNROLL 1           // state-pass unroll of the homogeneous model (measured: see DESIGN.md); per-neuron beta: 4
-#endif
 
 struct SpikeSeeds {
     float U[kMaxSpikes + 1];        // (c, 0, Z1, ..), fp32 (EventDrivenMap.cu:172)
@@ -46,12 +43,11 @@ struct SpikeSeeds {
 };
 
 // ---- LiftKernel (EventDrivenMap.cu:505-542), once per ComputeF -------------
+// one grid point; returns the synaptic variable it stored
 template <int MATH>
-__global__ __launch_bounds__(kMaxGrid) void lift_kernel(edm::Model M, SpikeSeeds sd, float* __restrict__ v,
-                                                        float* __restrict__ s)
+__device__ __forceinline__ float lift_point(const edm::Model& M, const SpikeSeeds& sd, unsigned i, float* __restrict__ v,
+                                            float* __restrict__ s, bool store)
 {
-    const unsigned i = threadIdx.x;
-    if (i >= M.N) return;
     const float c = sd.U[0], beta = M.beta_mean;
     const float a[2] = {M.a1, M.a2}, b[2] = {M.b1, M.b2};
     const float h = (2.0f * M.L) / (float)M.N;
@@ -103,8 +99,28 @@ __global__ __launch_bounds__(kMaxGrid) void lift_kernel(edm::Model M, SpikeSeeds
     }
     float vv = M.I + sv;
     vv = vv * ((vv < 1.0f) ? 1.0f : 0.0f);
-    v[i] = vv;
-    s[i] = ss;
+    if (store) {
+        v[i] = vv;
+        s[i] = ss;
+    }
+    return ss;
+}
+
+// aux[0] <- bit k set iff the 64-neuron slice k holds a neuron whose synaptic variable is not NaN (the slices Evolve
+// has to carry, see evolve_kernel)
+template <int MATH>
+__global__ __launch_bounds__(kMaxGrid) void lift_kernel(edm::Model M, SpikeSeeds sd, float* __restrict__ v,
+                                                        float* __restrict__ s, unsigned* __restrict__ aux)
+{
+    __shared__ unsigned live;
+    const unsigned i = threadIdx.x;
+    if (i == 0) live = 0u;
+    __syncthreads();
+    const unsigned ic = (i < M.N) ? i : M.N - 1u;      // lanes past the grid recompute the last point and store nothing
+    const float ss_ = lift_point<MATH>(M, sd, ic, v, s, i < M.N);
+    if (__any(i < M.N && ss_ == ss_) && (i & 63u) == 0u) atomicOr(&live, 1u << (i >> 6));
+    __syncthreads();
+    if (i == 0) aux[0] = live;
 }
 
 // Wave64 unsigned minimum with DPP row shifts + row broadcasts (gfx9 family), result broadcast to every lane.
@@ -134,34 +150,29 @@ __device__ __forceinline__ void wave_argmin(float& best, unsigned& idx)
     best = __uint_as_float(tmin);
 }
 
-// Experiment hook, compiled in with -DMI_EVOLVE_TIMING=1 only (scripts/gpu_evolve_phases.py): s_memtime ticks per wave,
-// summed over the grid, spent in [0] the Newton rounds, [1] arg-min + the uniform exponentials, [2] the state pass,
-// [3] the event bookkeeping; [4] events; [5], [6] 64-neuron slices of the state pass that reach will_fire's division / its
-// log and exp.
-#ifndef MI_EVOLVE_TIMING
-#define MI_EVOLVE_TIMING 0
-#endif
-#if MI_EVOLVE_TIMING
-__device__ unsigned long long g_evolve_ticks[8];
-#define MI_EV_STAMP(slot)                                              \
-    {                                                                  \
-        const unsigned long long tn_ = __builtin_readcyclecounter();   \
-        tacc[slot] += tn_ - tlast;                                     \
-        tlast = tn_;                                                   \
-    }
-#else
-#define MI_EV_STAMP(slot)
-#endif
-
 // ---- EvolveKernel (EventDrivenMap.cu:575-674): one wave64 per realisation ----
-// Neuron state lives in LDS, [wave][array][k*64 + lane]: every lane only ever
-// touches its own slots, so the event loop needs no barrier and the per-neuron
-// loop stays rolled (few VGPRs -> 3 workgroups per CU at N = 1024).
-// LDS per workgroup: w[1024] + 4 waves * (2 or 3) arrays * npl*64 floats.
+// Neuron state lives in LDS, [wave][array][slot*64 + lane]: every lane only ever touches its own slots, so the event
+// loop needs no barrier and the per-neuron loop stays rolled (63 VGPRs).
+//
+// Dead slices.  A 64-neuron slice whose every neuron starts with a NaN synaptic variable (the stretch that the lift
+// profile poisons through 0 * inf, LiftKernel :505-542 -- neurons 820..1023 at the reference's parameters, i.e. slices
+// 13-15 of 16) can never matter again: s' = s e3 + beta w stays NaN, v' = v e1 + (.. + (s e1 / (1 - beta)) (e2 - 1)) is NaN
+// after the first update, will_fire() is false for a NaN s, so such a neuron never fires, and as the arg-min's
+// winner (only when NO neuron fires) only its index is used.  The lift kernel reports the live slices as a bit mask
+// (`store`), the host sizes the LDS for those alone -- 13 slices: 4 + 4 * 6.5 KiB = 30 KiB per workgroup, FIVE
+// workgroups (20 waves) per CU instead of four -- and the state pass never visits the others; their standing
+// contribution to the arg-min, the time kNever at the lane's lowest dead index, is kept in nan_i.
+//
+// One workgroup per four realisations (launch_evolve): the hardware dispatcher hands them out as slots free up.
+// LDS per workgroup: w[1024] + 4 waves * (2 or 3) arrays * popcount(store)*64 floats.
 // NS: compile-time bound of the per-bump loops (3 = the reference's noSpikes, else kMaxSpikes)
 // UDIV: divisions by the homogeneous model's wave-uniform divisors through edm::div_by's five-operation exact quotient
-template <int MATH, bool HETERO, int NS, bool UDIV>
-__global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, SpikeSeeds sd,
+// TAPS: the same computation, also counting into taps[kTap*] how often it reaches the documented decisions
+//       (mi_edm_debug_counters; never what ComputeF launches)
+enum { kTapEvents = 0, kTapMaxEvents, kTapMaxNewton, kTapNewtonCap, kTapEventCap, kTapAccepted, kTapNoFiring, kTapTies, kTapCount };
+template <int MATH, bool HETERO, int NS, bool UDIV, bool TAPS = false>
+__global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, SpikeSeeds sd, unsigned store,
+                                                              unsigned long long* __restrict__ taps,
                                                               const float* __restrict__ v0,
                                                               const float* __restrict__ s0,
                                                               const float* __restrict__ w,
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned npl = (M.N + 63u) / 64u;
-    const unsigned slots = npl * 64u;
+    const unsigned slots = (unsigned)__builtin_popcount(store) * 64u;
     float* w_lds = lds;
     // homogeneous model: the table holds RN(beta * w[d]), the product every event would otherwise form again
     for (unsigned i = threadIdx.x; i < (unsigned)kMaxGrid; i += kEvolveBlock) {
@@ -186,31 +197,29 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
     float* V = lds + kMaxGrid + (size_t)wave * kArrays * slots;
     float* S = V + slots;
     float* B = S + slots;   // only touched when HETERO
-    const unsigned waves_per_grid = gridDim.x * (kEvolveBlock / 64);
     const unsigned full = (1u << M.S) - 1u;
     const float two_T = 2.0f * M.T;
+    // the same for every realisation: which of this lane's neurons exist in a live slice (bit k <-> neuron k*64+lane),
+    // and the lane's lowest neuron in a dead slice
+    unsigned valid = 0, nan_i = ~0u;
+    for (unsigned k = 0; k < npl; ++k) {
+        const unsigned i = k * 64u + lane;
+        if (i < M.N) {
+            if ((store >> k) & 1u) valid |= 1u << k;
+            else if (nan_i == ~0u) nan_i = i;
+        }
+    }
 
+    const unsigned waves_per_grid = gridDim.x * (kEvolveBlock / 64);
     for (unsigned r = blockIdx.x * (kEvolveBlock / 64) + wave; r < M.R; r += waves_per_grid) {
-        // Slices whose every neuron starts with v AND s NaN (the stretch that the lift profile poisons through 0 * inf,
-        // LiftKernel :505-542 -- 243 contiguous neurons at the reference's parameters): NaN stays NaN under every update
-        // of the event loop (v e1 + ..., (...) * 0 at a reset, s e3 + beta w), such a neuron never fires (will_fire is false
-        // for a NaN s) and is never the firing neuron, so the state pass skips these slices and only their standing
-        // contribution to the arg-min -- the time kNever at the lane's lowest such index -- is kept (nan_i).
-        unsigned skip = 0;            // bit k: slice k is all-NaN (wave-uniform)
-        unsigned nan_i = ~0u;         // this lane's lowest neuron index inside the skipped slices
-        unsigned valid = 0;           // bit k: neuron k*64+lane exists and its slice is advanced
-        for (unsigned k = 0; k < npl; ++k) {
-            const unsigned i = k * 64u + lane;
-            const bool act = i < M.N;
-            const float vi = act ? v0[i] : 0.0f, si = act ? s0[i] : 0.0f;
-            V[i] = vi;
-            S[i] = si;
-            if constexpr (HETERO) B[i] = edm::beta_of<MATH>(M.beta_mean, M.beta_sigma, M.seed, M.N, (uint64_t)r + M.real_offset, act ? i : 0u);
-            if (__all(!act || (vi != vi && si != si)) && __any(act)) {
-                skip |= 1u << k;
-                if (act && nan_i == ~0u) nan_i = i;
-            } else if (act) {
-                valid |= 1u << k;
+        {
+            unsigned a = lane;
+            for (unsigned m = store; m != 0u; m &= m - 1u, a += 64u) {
+                const unsigned i = (unsigned)__builtin_ctz(m) * 64u + lane;
+                const bool act = i < M.N;
+                V[a] = act ? v0[i] : 0.0f;
+                S[a] = act ? s0[i] : 0.0f;
+                if constexpr (HETERO) B[a] = edm::beta_of<MATH>(M.beta_mean, M.beta_sigma, M.seed, M.N, (uint64_t)r + M.real_offset, act ? i : 0u);
             }
         }
         // per-bump event slots ([D2]: start at time 0 / index 0); wave-uniform values
@@ -234,15 +243,16 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
         float base_t = INFINITY;      // min over this lane's non-firing neurons: kNever at the lowest such index
         unsigned base_i = 0;
         unsigned pend = 0;
-        for (unsigned k = 0; k < npl; ++k) {
-            if ((skip >> k) & 1u) continue;
-            const unsigned i = k * 64u + lane;
-            if (i < M.N) {
-                const float bk = HETERO ? B[i] : M.beta_mean;
-                if (edm::will_fire<MATH, UDIV && !HETERO>(M, V[i], S[i], bk)) pend |= (1u << k);
+        {
+            unsigned a = lane;
+            for (unsigned m = store; m != 0u; m &= m - 1u, a += 64u) {
+                const unsigned k = (unsigned)__builtin_ctz(m);
+                const float bk = HETERO ? B[a] : M.beta_mean;
+                if (edm::will_fire<MATH, UDIV && !HETERO>(M, V[a], S[a], bk)) pend |= (1u << k);
             }
+            pend &= valid;
         }
-        // the lane's lowest neuron that will not fire, from the masks (no per-slice tracking); the skipped slices' standing
+        // the lane's lowest neuron that will not fire, from the masks (no per-slice tracking); the dead slices' standing
         // candidate folded in
         auto lowest_quiet = [&]() {
             const unsigned quiet = ~pend & valid;
@@ -253,27 +263,36 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
         };
         lowest_quiet();
         unsigned events = 0;
-#if MI_EVOLVE_TIMING
-        unsigned long long tacc[4] = {0, 0, 0, 0};
-        unsigned nslow = 0, npow = 0;
-        unsigned long long tlast = __builtin_readcyclecounter();
-#endif
+        unsigned tap_newton = 0, tap_cap = 0, tap_quiet = 0, tap_ties = 0;      // (TAPS only)
         while (crossed < full && now < two_T && events < M.max_events) {
             ++events;
             float best = base_t;
             unsigned idx = base_i;
-            MI_EV_STAMP(3)
             while (__any(pend != 0u)) {
                 if (pend != 0u) {
                     const unsigned k = (unsigned)__builtin_ctz(pend);
                     pend &= pend - 1u;
                     const unsigned i = k * 64u + lane;
-                    const float bk = HETERO ? B[i] : M.beta_mean;
-                    const float tau = edm::newton_time<MATH, UDIV && !HETERO>(M, V[i], S[i], bk);
+                    const unsigned a = (unsigned)__builtin_popcount(store & ((1u << k) - 1u)) * 64u + lane;
+                    const float bk = HETERO ? B[a] : M.beta_mean;
+                    uint32_t it = 0;
+                    const float tau = edm::newton_time<MATH, UDIV && !HETERO>(M, V[a], S[a], bk, TAPS ? &it : nullptr);
+                    if constexpr (TAPS) {
+                        tap_newton = max(tap_newton, it);
+                        tap_cap += (it >= M.max_iter) ? 1u : 0u;
+                        tap_ties += (tau == best && tau < edm::kNever) ? 1u : 0u;      // two firing neurons of one lane
+                    }
                     if (tau < best || (tau == best && i < idx)) { best = tau; idx = i; }
                 }
             }
-            MI_EV_STAMP(0)
+            if constexpr (TAPS) {
+                const float mine = best;
+                float bb = best;
+                unsigned ii = idx;
+                wave_argmin(bb, ii);
+                if (bb >= edm::kNever) tap_quiet += 1u;
+                else if (__builtin_popcountll(__ballot(mine == bb)) > 1) tap_ties += 1u;   // ... or of two lanes
+            }
             wave_argmin(best, idx);
             // the winner is the same in every lane: in scalar registers the event bookkeeping below (nearest bump,
             // crossed mask) runs on the scalar unit
@@ -292,58 +311,30 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             } else {
                 e1 = edm::expf_<MATH>(-dt);
             }
-#if MI_EVOLVE_TIMING
-            asm volatile("" : "+v"(e2u), "+v"(e3u));
-#endif
-            MI_EV_STAMP(1)
-            constexpr int kStateUnroll = HETERO ? 4 : MI_EVOLVE_UNROLL;
+            constexpr int kStateUnroll = HETERO ? 4 : 1;      // measured (DESIGN_HISTORY.md): rolled, per-neuron beta 4x
+            unsigned a = lane;
 #pragma unroll kStateUnroll
-            for (unsigned k = 0; k < npl; ++k) {
-                if ((skip >> k) & 1u) continue;          // all-NaN slice: nothing to advance
+            for (unsigned m = store; m != 0u; m &= m - 1u, a += 64u) {      // live slices only
+                const unsigned k = (unsigned)__builtin_ctz(m);
                 const unsigned i = k * 64u + lane;
-                const float bk = HETERO ? B[i] : M.beta_mean;
+                const float bk = HETERO ? B[a] : M.beta_mean;
                 const float e2 = HETERO ? edm::expf_<MATH>((1.0f - bk) * dt) : e2u;
                 const float e3 = HETERO ? edm::expf_<MATH>(-bk * dt) : e3u;
-                const float so = S[i];
-                float vv = V[i] * e1;
+                const float so = S[a];
+                float vv = V[a] * e1;
                 vv = vv + (M.I * (1.0f - e1) + edm::div_by<MATH, UDIV && !HETERO>(so * e1, 1.0f - bk) * (e2 - 1.0f));
                 // reset of the neuron that fired (:615 multiplies every v by (tid != index)): x * 1 == x, so only that
                 // neuron needs the multiply (by 0: NaN stays NaN, a finite value becomes a signed zero)
                 vv = (i == idx) ? vv * 0.0f : vv;
                 float sn = so * e3;
-                const unsigned dist = (unsigned)abs((int)i - (int)idx);   // < kMaxGrid: i < slots <= kMaxGrid, idx < N
+                const unsigned dist = (unsigned)abs((int)i - (int)idx);   // < kMaxGrid: i < npl*64 <= kMaxGrid, idx < N
                 sn = sn + (HETERO ? bk * w_lds[dist] : w_lds[dist]);
-                V[i] = vv;
-                S[i] = sn;
-#if MI_EVOLVE_TIMING
-                if (__any(i < M.N && !(sn < 0.0f))) ++nslow;       // slices that reach will_fire's division
-                if (__any(i < M.N && sn >= 0.0f)) ++npow;          // ... and its log/exp
-#endif
+                V[a] = vv;
+                S[a] = sn;
                 if (edm::will_fire<MATH, UDIV && !HETERO>(M, vv, sn, bk)) pend |= (1u << k);   // (padding lanes: masked below)
             }
             pend &= valid;
-            if (events == 1u) {
-                // A neuron whose s starts NaN but whose v starts finite (the lift profile poisons s over a longer stretch than v:
-                // from neuron 820 and 857 of 1024 at the reference's parameters) has BOTH NaN after its first update (the
-                // division of so * e1 carries the NaN into v) and, like the neurons that start that way, for ever after.  So the
-                // set of all-NaN slices is final now: one more look, and the slices that joined it (one of sixteen at the
-                // reference's parameters) are skipped from the second event on.  Same rule as at t = 0: the slice's standing
-                // arg-min candidate (kNever at the lane's lowest index in a skipped slice) stays in nan_i.
-                for (unsigned k = 0; k < npl; ++k) {
-                    if ((skip >> k) & 1u) continue;
-                    const unsigned i = k * 64u + lane;
-                    const bool act = i < M.N;
-                    const float vi = V[i], si = S[i];
-                    if (__all(!act || (vi != vi && si != si)) && __any(act)) {
-                        skip |= 1u << k;
-                        valid &= ~(1u << k);
-                        if (act && i < nan_i) nan_i = i;
-                    }
-                }
-                pend &= valid;
-            }
             lowest_quiet();
-            MI_EV_STAMP(2)
             now = now + dt;
             // which bump does the event belong to ([D3]: the reference's increment rule, :625-629)
             unsigned mi = 0;
@@ -370,14 +361,6 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 if (after) crossed += (1u << mi);
             }
         }
-#if MI_EVOLVE_TIMING
-        if (lane == 0) {
-            for (int j = 0; j < 4; ++j) atomicAdd(&g_evolve_ticks[j], tacc[j]);
-            atomicAdd(&g_evolve_ticks[4], (unsigned long long)events);
-            atomicAdd(&g_evolve_ticks[5], (unsigned long long)nslow);
-            atomicAdd(&g_evolve_ticks[6], (unsigned long long)npow);
-        }
-#endif
         // [spike][realisation] layout, EventDrivenMap.cu:661-668
 #pragma unroll
         for (int m = 0; m < NS; ++m) {
@@ -390,6 +373,24 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             }
         }
         if (lane == 0) g_accept[r] = (crossed == full) ? 1u : 0u;
+        if constexpr (TAPS) {
+            unsigned mx = tap_newton, cap = tap_cap, ties = tap_ties;
+            for (int off = 32; off > 0; off >>= 1) {
+                mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+                cap += (unsigned)__shfl_xor((int)cap, off);
+                ties = max(ties, (unsigned)__shfl_xor((int)ties, off));
+            }
+            if (lane == 0) {
+                atomicAdd(&taps[kTapEvents], (unsigned long long)events);
+                atomicMax(&taps[kTapMaxEvents], (unsigned long long)events);
+                atomicMax(&taps[kTapMaxNewton], (unsigned long long)mx);
+                atomicAdd(&taps[kTapNewtonCap], (unsigned long long)cap);
+                atomicAdd(&taps[kTapEventCap], (crossed < full && events >= M.max_events) ? 1ull : 0ull);
+                atomicAdd(&taps[kTapAccepted], (crossed == full) ? 1ull : 0ull);
+                atomicAdd(&taps[kTapNoFiring], (unsigned long long)tap_quiet);
+                atomicAdd(&taps[kTapTies], (unsigned long long)ties);
+            }
+        }
     }
 }
 
@@ -633,6 +634,9 @@ struct mi_edm {
     char* d_one = nullptr;         // dedup_identical: events of the one evolved realisation (kOneBytes)
     char* d_result = nullptr;      // mean f32[8] | count u32 (+pad) | sums f64[8]
     char* h_result = nullptr;      // pinned mirror
+    unsigned* d_aux = nullptr;     // [0] live-slice mask written by the lift kernel
+    unsigned* h_aux = nullptr;     // pinned mirror of d_aux[0]
+    SpikeSeeds last_sd;            // seeds of the last evaluation (mi_edm_debug_counters re-runs Evolve with them)
     size_t alloc_real = 0;
     bool w_valid = false;
     bool have_run = false;
@@ -756,19 +760,35 @@ void seed_indices(const mi_edm_params& p, const double* Z, uint16_t* ind)
     }
 }
 
+// which form of the evolve kernel a launch takes: 1 = one wave per realisation (throughput), 4 = one workgroup of four
+// waves per realisation (latency).  MI_EDM_WAVES_PER_REALISATION = 1 | 4 (read at mi_edm_create) overrides the choice.
+int evolve_form(const mi_edm* e)
+{
+    const bool hetero = e->p.beta_stddev != 0.0f;
+    const bool dedup = e->p.dedup_identical != 0 && !hetero && e->p.n_real > 1;
+    const unsigned Reff = dedup ? 1u : e->p.n_real;
+    return e->waves_per_real ? e->waves_per_real : ((Reff < kWgNarrow) ? 4 : 1);
+}
+
+// live: the lift kernel's live-slice mask (wave-per-realisation form only; ignored by the latency form)
 template <int MATH>
-mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd)
+mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
 {
     mi_ctx* ctx = e->ctx;
     const unsigned N = e->p.n_grid, R = e->p.n_real;
-    const unsigned slots = ((N + 63) / 64) * 64;
     const bool hetero = e->p.beta_stddev != 0.0f;
-    const size_t lds_bytes = ((size_t)kMaxGrid + (size_t)(kEvolveBlock / 64) * (hetero ? 3 : 2) * slots) * sizeof(float);
+    const unsigned cus = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256);
+    const size_t lds_bytes = ((size_t)kMaxGrid + (size_t)(kEvolveBlock / 64) * (hetero ? 3 : 2) * 64u * (unsigned)__builtin_popcount(live)) * sizeof(float);
+    // One workgroup per four realisations, however many that is: the hardware's workgroup dispatcher then IS the work
+    // queue (a finished workgroup's slot goes to the next four realisations; per-workgroup set-up is the 4 KiB coupling
+    // table, microseconds against milliseconds per realisation), so the launch ends within one realisation's time of the
+    // ideal.  A grid capped at a multiple of the resident set left waves with 6 or 7 realisations each and a ragged end.
+    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));   // residency by LDS
     unsigned blocks = (R + 3) / 4;
-    // grid-stride over realisations: enough workgroups for every CU at the LDS-limited residency
-    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
-    const unsigned cap = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256) * per_cu * 4u;
-    if (blocks > cap) blocks = cap;
+    if (const char* env = getenv("MI_EDM_GRID_ROUNDS")) {      // experiment hook: cap the grid at env x the resident set
+        const unsigned cap = cus * per_cu * (unsigned)std::max(1, atoi(env));
+        if (blocks > cap) blocks = cap;
+    }
     // dedup_identical: without heterogeneity the realisations are R copies of one computation
     const bool dedup = e->p.dedup_identical != 0 && !hetero && R > 1;
     edm::Model M = e->M;
@@ -785,18 +805,16 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd)
         accept = (uint32_t*)(e->d_one + kOneAccept);
     }
     // Few realisations: spread each one over a workgroup of 4 waves (evolve_wg_kernel, bit-identical results).
-    // MI_EDM_WAVES_PER_REALISATION = 1 | 4 (read at mi_edm_create) overrides the choice (test / tuning hook).
     const unsigned Reff = M.R;
-    const int wpr = e->waves_per_real ? e->waves_per_real : ((Reff < kWgNarrow) ? 4 : 1);
+    const int wpr = evolve_form(e);
     const bool three = e->p.n_spikes <= 3;
     if (wpr == 1) {
 #define MI_EVOLVE(H, NS, UD)                                                                                      \
     hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, UD>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, M, sd, \
-                       e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept)
+                       live, nullptr, e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept)
         // The exact quotient by uniform divisors pays where there are waves enough to hide its (longer) dependent chain:
         // the LDS leaving six or more per SIMD (N <= 640) and the launch bringing three or more.  N = 512: R = 16384
         // 10.25 -> 9.00 ms, R = 4000 3.10 -> 2.91 ms, but R = 1000 (one wave per SIMD) 1.59 -> 2.10 ms.
-        const unsigned cus = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256);
         const bool udiv = MATH == 0 && !hetero && per_cu >= 6 && Reff >= cus * 12u && !e->no_uniform_div;
         if (hetero) { if (three) MI_EVOLVE(true, 3, false); else MI_EVOLVE(true, kMaxSpikes, false); }
         else if (udiv) { if (three) MI_EVOLVE(false, 3, true); else MI_EVOLVE(false, kMaxSpikes, true); }
@@ -804,6 +822,7 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd)
 #undef MI_EVOLVE
     } else {
         const unsigned bt = 64u * (unsigned)wpr;
+        (void)live;
         const unsigned wslots = ((N + bt - 1) / bt) * bt;
         const size_t wlds = ((size_t)kMaxGrid + (size_t)(hetero ? 3 : 2) * wslots) * sizeof(float) + (size_t)4 * wpr * sizeof(unsigned);
         const unsigned wper_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / wlds));
@@ -837,10 +856,27 @@ mi_status run_pipeline(mi_edm* e, const SpikeSeeds& sd)
         e->w_valid = true;
     }
     MI_HIP(ctx, hipEventRecord(e->ev[0], ctx->stream));
-    hipLaunchKernelGGL((lift_kernel<MATH>), dim3(1), dim3(kMaxGrid), 0, ctx->stream, e->M, sd, e->d_v, e->d_s);
+    hipLaunchKernelGGL((lift_kernel<MATH>), dim3(1), dim3(kMaxGrid), 0, ctx->stream, e->M, sd, e->d_v, e->d_s, e->d_aux);
     MI_LAUNCH_CHECK(ctx, "lift kernel");
     MI_HIP(ctx, hipEventRecord(e->ev[1], ctx->stream));
-    mi_status st = launch_evolve<MATH>(e, sd);
+    // The throughput form sizes its LDS (hence its residency: five workgroups per CU instead of four at the reference's
+    // parameters) by the number of live slices, which only the lift profile knows: one 4-byte read-back and a wait for the
+    // lift kernel (tens of microseconds against an evolve of tens of milliseconds).  The latency form carries every slice
+    // and does not wait.
+    unsigned live = 0;
+    if (evolve_form(e) == 1) {
+        if (getenv("MI_EDM_TRACE")) fprintf(stderr, "trace: before live read-back\n");
+        MI_HIP(ctx, hipMemcpyAsync(e->h_aux, e->d_aux, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        live = *e->h_aux;
+        if (getenv("MI_EDM_TRACE")) fprintf(stderr, "trace: live = 0x%x\n", live);
+    }
+    mi_status st = launch_evolve<MATH>(e, sd, live);
+    if (getenv("MI_EDM_TRACE")) {
+        fprintf(stderr, "trace: evolve launched (status %d)\n", (int)st);
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "trace: evolve done (%s)\n", hipGetErrorString(e2));
+    }
     if (st != MI_OK) return st;
     MI_HIP(ctx, hipEventRecord(e->ev[2], ctx->stream));
     st = mi_restrict_mean_f32_dev(ctx, e->d_t0, e->d_i0, e->d_t1, e->d_i1, e->d_accept, e->p.time_horizon, e->p.L,
@@ -904,7 +940,9 @@ mi_status mi_edm_create(mi_ctx* ctx, const mi_edm_params* p, mi_edm** out)
     if (err == hipSuccess) err = hipMalloc(&e->d_w, kMaxGrid * sizeof(float));
     if (err == hipSuccess) err = hipMalloc(&e->d_result, kResultBytes);
     if (err == hipSuccess) err = hipMalloc(&e->d_one, kOneBytes);
+    if (err == hipSuccess) err = hipMalloc(&e->d_aux, 2 * sizeof(unsigned));
     if (err == hipSuccess) err = hipHostMalloc(&e->h_result, kResultBytes);
+    if (err == hipSuccess) err = hipHostMalloc(&e->h_aux, sizeof(unsigned));
     for (int i = 0; i < 4 && err == hipSuccess; ++i) err = hipEventCreate(&e->ev[i]);
     if (err != hipSuccess) {
         mi_edm_destroy(e);
@@ -924,10 +962,11 @@ mi_status mi_edm_destroy(mi_edm* e)
     // (the context itself may already be gone: the Python layer closes handles in arbitrary order at interpreter exit)
     if (e->pending) (void)hipStreamSynchronize(e->pending_stream);
     free_real_buffers(e);
-    void* bufs[] = {e->d_v, e->d_s, e->d_w, e->d_result, e->d_one};
+    void* bufs[] = {e->d_v, e->d_s, e->d_w, e->d_result, e->d_one, e->d_aux};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (e->h_result) (void)hipHostFree(e->h_result);
+    if (e->h_aux) (void)hipHostFree(e->h_aux);
     for (int i = 0; i < 4; ++i)
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     delete e;
@@ -970,6 +1009,7 @@ mi_status mi_edm_compute_f_begin(mi_edm* e, const double* z)
     for (uint32_t i = 0; i <= S; ++i) sd.U[i] = (float)U0[i];
     seed_indices(e->p, z, e->seed_ind);
     for (uint32_t m = 0; m < S; ++m) sd.ind[m] = e->seed_ind[m];
+    e->last_sd = sd;
     // marked before the first launch: if run_pipeline fails half-way, kernels already enqueued still use the buffers,
     // and mi_edm_destroy / mi_edm_set_params synchronise only when they see work pending
     e->pending = true;
@@ -1066,6 +1106,53 @@ mi_status mi_edm_debug_read(mi_edm* e, float* v, float* s, float* w, float* t0, 
     return MI_OK;
 }
 
+// Decision-coverage taps (the device-side mirror of oracle/edm_oracle.c's orc_edm_counters): Evolve of the LAST ComputeF
+// is run again by the tapped instantiation of the wave-per-realisation kernel (same arithmetic, same outputs, plus
+// counters).  The product launch carries none of this.
+mi_status mi_edm_debug_counters(mi_edm* e, uint64_t out[MI_EDM_N_COUNTERS])
+{
+    MI_REQUIRE(nullptr, e != nullptr, "mi_edm_debug_counters: handle is NULL");
+    mi_ctx* ctx = e->ctx;
+    MI_REQUIRE(ctx, out != nullptr, "mi_edm_debug_counters: NULL argument");
+    MI_REQUIRE(ctx, e->have_run && !e->pending, "mi_edm_debug_counters: no ComputeF has completed with the current parameters");
+    MI_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long* d_taps = nullptr;
+    MI_HIP(ctx, hipMalloc(&d_taps, kTapCount * sizeof(unsigned long long)));
+    mi_status st = MI_OK;
+    hipError_t err = hipMemsetAsync(d_taps, 0, kTapCount * sizeof(unsigned long long), ctx->stream);
+    unsigned live = 0;
+    if (err == hipSuccess) err = hipMemcpyAsync(&live, e->d_aux, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    if (err == hipSuccess) {
+        const bool hetero = e->p.beta_stddev != 0.0f, three = e->p.n_spikes <= 3;
+        const size_t lds_bytes = ((size_t)kMaxGrid + (size_t)(kEvolveBlock / 64) * (hetero ? 3 : 2) * 64u * (unsigned)__builtin_popcount(live)) * sizeof(float);
+        const unsigned cus = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256);
+        const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
+        const unsigned blocks = std::min<unsigned>((e->p.n_real + 3) / 4, cus * per_cu);
+#define MI_TAPPED(MATH, H, NS)                                                                                              \
+    hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, false, true>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
+                       e->M, e->last_sd, live, d_taps, e->d_v, e->d_s, e->d_w, e->d_t0, e->d_i0, e->d_t1,     \
+                       e->d_i1, e->d_accept)
+        if (e->p.math_mode == MI_EDM_MATH_FAST) {
+            if (hetero) { if (three) MI_TAPPED(1, true, 3); else MI_TAPPED(1, true, kMaxSpikes); }
+            else { if (three) MI_TAPPED(1, false, 3); else MI_TAPPED(1, false, kMaxSpikes); }
+        } else {
+            if (hetero) { if (three) MI_TAPPED(0, true, 3); else MI_TAPPED(0, true, kMaxSpikes); }
+            else { if (three) MI_TAPPED(0, false, 3); else MI_TAPPED(0, false, kMaxSpikes); }
+        }
+#undef MI_TAPPED
+        err = hipGetLastError();
+    }
+    unsigned long long h[kTapCount] = {0};
+    if (err == hipSuccess) err = hipMemcpyAsync(h, d_taps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_taps);
+    if (err != hipSuccess) st = mi::fail(ctx, MI_ERR_HIP, "mi_edm_debug_counters failed: %s", hipGetErrorString(err));
+    static_assert(kTapCount == MI_EDM_N_COUNTERS, "tap layout and ABI constant disagree");
+    for (int i = 0; i < kTapCount; ++i) out[i] = (uint64_t)h[i];
+    return st;
+}
+
 mi_status mi_edm_last_timings(mi_edm* e, float ms[4])
 {
     MI_REQUIRE(nullptr, e && ms, "mi_edm_last_timings: NULL argument");
@@ -1092,13 +1179,3 @@ mi_status mi_edm_math_probe(mi_ctx* ctx, int math_mode, int op, const float* a_d
 
 }  // extern "C"
 
-#if MI_EVOLVE_TIMING
-// experiment hook (not part of the ABI; only in -DMI_EVOLVE_TIMING=1 builds): read and clear the evolve phase ticks
-extern "C" int mi_debug_evolve_timing(unsigned long long* out8)
-{
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipDeviceSynchronize() != hipSuccess) return 1;
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_evolve_ticks), sizeof(z)) != hipSuccess) return 1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_evolve_ticks), z, sizeof(z)) == hipSuccess ? 0 : 1;
-}
-#endif

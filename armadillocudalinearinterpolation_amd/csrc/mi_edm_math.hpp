@@ -271,8 +271,9 @@ MI_HD bool will_fire(const Model& M, float v0, float s0, float beta)
     return v0 > thr;
 }
 
+// iters (optional, debug taps): receives the number of iterations taken
 template <int MATH, bool UNI = false>
-MI_HD float newton_time(const Model& M, float v0, float s0, float beta)
+MI_HD float newton_time(const Model& M, float v0, float s0, float beta, uint32_t* iters = nullptr)
 {
     float t = 0.0f;
     FdF r = fun_dfun_e<MATH, UNI>(M, 1.0f, 1.0f, v0, s0, beta);
@@ -285,6 +286,7 @@ MI_HD float newton_time(const Model& M, float v0, float s0, float beta)
         df = r.df;
         ++counter;
     }
+    if (iters) *iters = counter;
     return fabsf(t);
 }
 

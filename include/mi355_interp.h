@@ -299,6 +299,17 @@ mi_status mi_edm_residual_from_sums(const mi_edm_params* p, const double* z, con
 mi_status mi_edm_debug_read(mi_edm* e, float* v, float* s, float* w, float* t0, uint16_t* i0,
                             float* t1, uint16_t* i1, uint32_t* accept, float* restricted,
                             uint16_t* seed_ind);
+/* Decision-coverage taps of the last compute_f (the device-side mirror of the oracle's orc_edm_counters,
+ * oracle/edm_oracle.c): the evolve stage is run once more by an instantiation of the kernel that also counts
+ *   [0] events of all realisations   [1] most events of one realisation   [2] most Newton iterations of one
+ *   firing-time solve (eventTime, EventDrivenMap.cu:561-571)   [3] solves that stopped at newton_max_iter (the
+ *   reference's undefined counterMax, :564)   [4] realisations that left the event loop at max_events
+ *   [5] accepted realisations   [6] events at which NO neuron will fire (every candidate time is the "never"
+ *   value 100.0f: the block arg-min of :843-881 is then decided by its tie rule)   [7] events at which two
+ *   neurons share the minimal REAL firing time (lower bound).
+ * Debug only: allocates, synchronises, and costs one more evolve. */
+#define MI_EDM_N_COUNTERS 8
+mi_status mi_edm_debug_counters(mi_edm* e, uint64_t out[MI_EDM_N_COUNTERS]);
 /* duration of the stages of the last compute_f in ms (HIP events):
  * [0] lift, [1] evolve, [2] restrict+mean, [3] whole call */
 mi_status mi_edm_last_timings(mi_edm* e, float ms[4]);

@@ -410,3 +410,32 @@ def test_config4_per_gpu_share_125k_realisations(mi_ctx):
     ft, pt = edm.ComputeF(Z_DRIVER, want_partial=True)
     assert np.array_equal(ft, fref(R, False)) and np.array_equal(pt[:3], R * x) and pt[3] == R
     edm.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_grid=1024, n_real=6),                                  # config 4's grid, Driver.cu:24's inputs
+    dict(n_grid=512, n_real=6),                                   # Driver.cu:69's grid
+    dict(n_grid=1024, n_real=5, beta_stddev=0.3, seed=7),         # per-neuron beta
+    dict(n_grid=1024, n_real=3, max_events=10),                   # event cap reached (D8)
+    dict(n_grid=512, n_real=3, newton_max_iter=2),                # Newton cap reached (D0)
+])
+def test_device_decision_counters_equal_the_oracles(mi_ctx, kw):
+    """mi_edm_debug_counters re-runs Evolve with the tapped instantiation of the kernel: its counts of events, Newton
+    iterations, cap hits and no-firing events must equal oracle/edm_oracle.c's orc_edm_counters on the same inputs --
+    and at the BASELINE inputs (first two cases) none of the documented decisions D0 / D1 / D8 is reached on the device
+    either (tests/test_edm_oracle_cpu.py states the same over the whole config-5 solve on the CPU)."""
+    kw = dict(kw)
+    edm, f, partial, dbg = _run(mi_ctx, **dict(kw))
+    dev = edm.debug_counters()
+    again = edm.debug_read()                                       # the tapped run must leave the very same events behind
+    for k in ("t0", "i0", "t1", "i1", "accept"):
+        assert np.array_equal(again[k], dbg[k], equal_nan=True), k
+    c = oracle.EdmCounters()
+    oracle.edm_compute_f(oracle.edm_default_params(**kw), Z_DRIVER, nthreads=8, counters=c)
+    o = c.as_dict()
+    for name in ("events", "max_events_one", "max_newton_iter", "newton_cap_hits", "event_cap_hits", "accepted", "no_firing_events"):
+        assert dev[name] == o[name], (name, dev, o)
+    assert (dev["argmin_ties"] > 0) == (o["argmin_ties"] > 0)
+    if set(kw) <= {"n_grid", "n_real"}:
+        assert dev["newton_cap_hits"] == dev["event_cap_hits"] == dev["no_firing_events"] == dev["argmin_ties"] == 0
+        assert dev["accepted"] == kw["n_real"] and dev["max_newton_iter"] <= 12
