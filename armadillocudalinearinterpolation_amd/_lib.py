@@ -107,6 +107,7 @@ SIGNATURES = {
     "mi_edm_create": (_i32, [_vp, C.POINTER(EdmParams), _pp]),
     "mi_edm_destroy": (_i32, [_vp]),
     "mi_edm_set_params": (_i32, [_vp, C.POINTER(EdmParams)]),
+    "mi_edm_set_kernel_choice": (_i32, [_vp, _i32, _i32]),
     "mi_edm_compute_f": (_i32, [_vp, _vp, _vp, _vp]),
     "mi_edm_compute_f_begin": (_i32, [_vp, _vp]),
     "mi_edm_compute_f_end": (_i32, [_vp, _vp, _vp]),

@@ -8,6 +8,7 @@ Names follow the reference's domain: grids / nodes / queries for the tables,
 realisations / spikes for EventDrivenMap (EventDrivenMap.hpp:11-121).
 """
 import ctypes as C
+import os
 import math
 import weakref
 
@@ -367,11 +368,20 @@ class EventDrivenMap:
         h = C.c_void_p()
         check(self._L.mi_edm_create(ctx._h, C.byref(self.params), C.byref(h)), ctx._h)
         self._h = h
+        # test / tuning hooks of the Python layer (the library itself reads no environment for this): force an evolve
+        # kernel form, switch the exact quotient by launch-uniform divisors off.  Results are bit-identical either way.
+        wpr = os.environ.get("MI_EDM_WAVES_PER_REALISATION", "")
+        if wpr in ("1", "4") or "MI_EDM_NO_UNIFORM_DIV" in os.environ:
+            self.set_kernel_choice(int(wpr) if wpr in ("1", "4") else 0, "MI_EDM_NO_UNIFORM_DIV" not in os.environ)
         if hasattr(ctx, "_children"):
             ctx._children.add(self)
 
     def _push(self):
         check(self._L.mi_edm_set_params(self._h, C.byref(self.params)), self._ctx._h)
+
+    def set_kernel_choice(self, waves_per_realisation=0, uniform_division=True):
+        """mi_edm_set_kernel_choice: 0 / 1 / 4 waves per realisation, exact quotient by uniform divisors on / off."""
+        check(self._L.mi_edm_set_kernel_choice(self._h, int(waves_per_realisation), int(bool(uniform_division))), self._ctx._h)
 
     # setters of EventDrivenMap.hpp:27-51
     def SetTimeHorizon(self, T):

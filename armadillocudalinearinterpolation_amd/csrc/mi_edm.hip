@@ -164,7 +164,8 @@ __device__ __forceinline__ void wave_argmin(float& best, unsigned& idx)
 // contribution to the arg-min, the time kNever at the lane's lowest dead index, is kept in nan_i.
 //
 // One workgroup per four realisations (launch_evolve): the hardware dispatcher hands them out as slots free up.
-// LDS per workgroup: w[1024] + 4 waves * (2 or 3) arrays * popcount(store)*64 floats.
+// LDS per workgroup: w[1024] + 4 waves * (2 or 3) arrays * popcount(store)*64 floats + 4 * 64 pending-neuron slots
+// (evolve_lds_bytes).
 // NS: compile-time bound of the per-bump loops (3 = the reference's noSpikes, else kMaxSpikes)
 // UDIV: divisions by the homogeneous model's wave-uniform divisors through edm::div_by's five-operation exact quotient
 // TAPS: the same computation, also counting into taps[kTap*] how often it reaches the documented decisions
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
     float* V = lds + kMaxGrid + (size_t)wave * kArrays * slots;
     float* S = V + slots;
     float* B = S + slots;   // only touched when HETERO
+    unsigned* list = reinterpret_cast<unsigned*>(lds + kMaxGrid + (size_t)(kEvolveBlock / 64) * kArrays * slots) + wave * 64u;   // this wave's pending neurons
     const unsigned full = (1u << M.S) - 1u;
     const float two_T = 2.0f * M.T;
     // the same for every realisation: which of this lane's neurons exist in a live slice (bit k <-> neuron k*64+lane),
@@ -268,6 +270,44 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             ++events;
             float best = base_t;
             unsigned idx = base_i;
+            // Firing-time solves, one round = the lowest pending neuron of every lane.  Which lane solves a neuron does not
+            // matter: the minimum below is lexicographic in (time, neuron index).
+            if constexpr (MATH == 0) {
+            // EXACT math: the round's neurons are compacted into `list` (rank by v_mbcnt over the ballot) and each goes to a
+            // lane PAIR (j, j + 32) that shares the two software exponentials and the two IEEE divisions of a Newton
+            // iteration (edm::newton_time_paired): 138 instead of 149 ms per 125 000 x 1024 ComputeF.
+            while (__any(pend != 0u)) {
+                const bool has = pend != 0u;
+                const unsigned long long bal = __ballot(has);
+                const unsigned total = (unsigned)__builtin_popcountll(bal);
+                if (has) {
+                    const unsigned k = (unsigned)__builtin_ctz(pend);
+                    pend &= pend - 1u;
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    list[rank] = k * 64u + lane;
+                }
+                for (unsigned base = 0; base < total; base += 32u) {      // (wave-uniform; more than once only with > 32 solves)
+                    const unsigned j = base + (lane & 31u);
+                    if (j < total) {
+                        const unsigned i = list[j];
+                        const unsigned k = i >> 6;
+                        const unsigned a = (unsigned)__builtin_popcount(store & ((1u << k) - 1u)) * 64u + (i & 63u);
+                        const float bk = HETERO ? B[a] : M.beta_mean;
+                        uint32_t it = 0;
+                        const float tau = edm::newton_time_paired<MATH, UDIV && !HETERO>(M, V[a], S[a], bk, lane >= 32u, TAPS ? &it : nullptr);
+                        if (lane < 32u) {
+                            if constexpr (TAPS) {
+                                tap_newton = max(tap_newton, it);
+                                tap_cap += (it >= M.max_iter) ? 1u : 0u;
+                                tap_ties += (tau == best && tau < edm::kNever) ? 1u : 0u;      // two firing neurons met in one lane
+                            }
+                            if (tau < best || (tau == best && i < idx)) { best = tau; idx = i; }
+                        }
+                    }
+                }
+            }
+            } else {
+            // FAST math (hardware exp and reciprocal: nothing worth sharing, the pairing costs 10 %): every lane solves its own
             while (__any(pend != 0u)) {
                 if (pend != 0u) {
                     const unsigned k = (unsigned)__builtin_ctz(pend);
@@ -280,10 +320,11 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                     if constexpr (TAPS) {
                         tap_newton = max(tap_newton, it);
                         tap_cap += (it >= M.max_iter) ? 1u : 0u;
-                        tap_ties += (tau == best && tau < edm::kNever) ? 1u : 0u;      // two firing neurons of one lane
+                        tap_ties += (tau == best && tau < edm::kNever) ? 1u : 0u;
                     }
                     if (tau < best || (tau == best && i < idx)) { best = tau; idx = i; }
                 }
+            }
             }
             if constexpr (TAPS) {
                 const float mine = best;
@@ -615,6 +656,7 @@ __global__ void math_probe_kernel(int op, const float* a, const float* b, float*
                          : (edm::will_fire<MATH, false, false>(M, a[i], b[i], beta) ? 1.0f : 0.0f);
             break;
         }
+        case 12: r = edm::other_half(a[i], (threadIdx.x & 32u) != 0u); break;   // a[i ^ 32]: the lane-pair exchange of the paired solves
         default: r = edm::erfinvf_<MATH>(a[i]); break;
     }
     out[i] = r;
@@ -647,9 +689,9 @@ struct mi_edm {
     uint16_t seed_ind[kMaxSpikes] = {0};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};
-    // test / tuning hooks, read from the environment ONCE per handle (mi_edm_create), never per launch:
-    int waves_per_real = 0;            // MI_EDM_WAVES_PER_REALISATION = 1 | 4 forces an evolve kernel form (0: by realisation count)
-    bool no_uniform_div = false;       // MI_EDM_NO_UNIFORM_DIV: never take the exact quotient by wave-uniform divisors
+    // test / tuning knobs (mi_edm_set_kernel_choice); every choice gives bit-identical results
+    int waves_per_real = 0;            // 1 | 4 forces an evolve kernel form (0: by realisation count)
+    bool no_uniform_div = false;       // never take the exact quotient by wave-uniform divisors
 };
 
 namespace {
@@ -760,8 +802,14 @@ void seed_indices(const mi_edm_params& p, const double* Z, uint16_t* ind)
     }
 }
 
+// dynamic LDS of evolve_kernel: coupling table, the live slices' state per wave, the per-wave pending-neuron lists
+size_t evolve_lds_bytes(bool hetero, unsigned live)
+{
+    return ((size_t)kMaxGrid + (size_t)(kEvolveBlock / 64) * ((hetero ? 3 : 2) * 64u * (unsigned)__builtin_popcount(live) + 64u)) * sizeof(float);
+}
+
 // which form of the evolve kernel a launch takes: 1 = one wave per realisation (throughput), 4 = one workgroup of four
-// waves per realisation (latency).  MI_EDM_WAVES_PER_REALISATION = 1 | 4 (read at mi_edm_create) overrides the choice.
+// waves per realisation (latency).  mi_edm_set_kernel_choice overrides the choice.
 int evolve_form(const mi_edm* e)
 {
     const bool hetero = e->p.beta_stddev != 0.0f;
@@ -778,17 +826,13 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
     const unsigned N = e->p.n_grid, R = e->p.n_real;
     const bool hetero = e->p.beta_stddev != 0.0f;
     const unsigned cus = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256);
-    const size_t lds_bytes = ((size_t)kMaxGrid + (size_t)(kEvolveBlock / 64) * (hetero ? 3 : 2) * 64u * (unsigned)__builtin_popcount(live)) * sizeof(float);
+    const size_t lds_bytes = evolve_lds_bytes(hetero, live);
     // One workgroup per four realisations, however many that is: the hardware's workgroup dispatcher then IS the work
     // queue (a finished workgroup's slot goes to the next four realisations; per-workgroup set-up is the 4 KiB coupling
     // table, microseconds against milliseconds per realisation), so the launch ends within one realisation's time of the
     // ideal.  A grid capped at a multiple of the resident set left waves with 6 or 7 realisations each and a ragged end.
-    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));   // residency by LDS
+    // (profiles/r04_edm_grid_rounds.log: grid capped at 1 / 2 / 4 x the resident set 181 / 166 / 157 ms, uncapped 149 ms.)
     unsigned blocks = (R + 3) / 4;
-    if (const char* env = getenv("MI_EDM_GRID_ROUNDS")) {      // experiment hook: cap the grid at env x the resident set
-        const unsigned cap = cus * per_cu * (unsigned)std::max(1, atoi(env));
-        if (blocks > cap) blocks = cap;
-    }
     // dedup_identical: without heterogeneity the realisations are R copies of one computation
     const bool dedup = e->p.dedup_identical != 0 && !hetero && R > 1;
     edm::Model M = e->M;
@@ -812,10 +856,10 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
 #define MI_EVOLVE(H, NS, UD)                                                                                      \
     hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, UD>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, M, sd, \
                        live, nullptr, e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept)
-        // The exact quotient by uniform divisors pays where there are waves enough to hide its (longer) dependent chain:
-        // the LDS leaving six or more per SIMD (N <= 640) and the launch bringing three or more.  N = 512: R = 16384
-        // 10.25 -> 9.00 ms, R = 4000 3.10 -> 2.91 ms, but R = 1000 (one wave per SIMD) 1.59 -> 2.10 ms.
-        const bool udiv = MATH == 0 && !hetero && per_cu >= 6 && Reff >= cus * 12u && !e->no_uniform_div;
+        // The exact quotient by uniform divisors (edm::div_by) pays once the launch brings three or more waves per SIMD
+        // (N = 512: R = 16384 10.25 -> 9.00 ms, R = 4000 3.10 -> 2.91 ms, but R = 1000 -- one wave per SIMD -- 1.59 -> 2.10 ms).
+        // Round 4: with its guard down to three integer instructions it also pays at N = 1024 (137.7 -> 134.2 ms at R = 125 000).
+        const bool udiv = MATH == 0 && !hetero && Reff >= cus * 12u && !e->no_uniform_div;
         if (hetero) { if (three) MI_EVOLVE(true, 3, false); else MI_EVOLVE(true, kMaxSpikes, false); }
         else if (udiv) { if (three) MI_EVOLVE(false, 3, true); else MI_EVOLVE(false, kMaxSpikes, true); }
         else { if (three) MI_EVOLVE(false, 3, false); else MI_EVOLVE(false, kMaxSpikes, false); }
@@ -865,18 +909,11 @@ mi_status run_pipeline(mi_edm* e, const SpikeSeeds& sd)
     // and does not wait.
     unsigned live = 0;
     if (evolve_form(e) == 1) {
-        if (getenv("MI_EDM_TRACE")) fprintf(stderr, "trace: before live read-back\n");
         MI_HIP(ctx, hipMemcpyAsync(e->h_aux, e->d_aux, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
         live = *e->h_aux;
-        if (getenv("MI_EDM_TRACE")) fprintf(stderr, "trace: live = 0x%x\n", live);
     }
     mi_status st = launch_evolve<MATH>(e, sd, live);
-    if (getenv("MI_EDM_TRACE")) {
-        fprintf(stderr, "trace: evolve launched (status %d)\n", (int)st);
-        hipError_t e2 = hipStreamSynchronize(ctx->stream);
-        fprintf(stderr, "trace: evolve done (%s)\n", hipGetErrorString(e2));
-    }
     if (st != MI_OK) return st;
     MI_HIP(ctx, hipEventRecord(e->ev[2], ctx->stream));
     st = mi_restrict_mean_f32_dev(ctx, e->d_t0, e->d_i0, e->d_t1, e->d_i1, e->d_accept, e->p.time_horizon, e->p.L,
@@ -929,11 +966,6 @@ mi_status mi_edm_create(mi_ctx* ctx, const mi_edm_params* p, mi_edm** out)
     e->device = ctx->device;
     e->p = *p;
     fill_model(e->p, &e->M);
-    if (const char* env = getenv("MI_EDM_WAVES_PER_REALISATION")) {
-        const int v = atoi(env);
-        if (v == 1 || v == 4) e->waves_per_real = v;
-    }
-    e->no_uniform_div = getenv("MI_EDM_NO_UNIFORM_DIV") != nullptr;
     hipError_t err = hipSuccess;
     if (err == hipSuccess) err = hipMalloc(&e->d_v, kMaxGrid * sizeof(float));
     if (err == hipSuccess) err = hipMalloc(&e->d_s, kMaxGrid * sizeof(float));
@@ -989,6 +1021,17 @@ mi_status mi_edm_set_params(mi_edm* e, const mi_edm_params* p)
     e->w_valid = w_same;
     e->have_run = false;
     return ensure_buffers(e);
+}
+
+mi_status mi_edm_set_kernel_choice(mi_edm* e, int waves_per_realisation, int uniform_division)
+{
+    MI_REQUIRE(nullptr, e != nullptr, "mi_edm_set_kernel_choice: handle is NULL");
+    MI_REQUIRE(e->ctx, waves_per_realisation == 0 || waves_per_realisation == 1 || waves_per_realisation == 4,
+               "mi_edm_set_kernel_choice: waves_per_realisation must be 0 (automatic), 1 or 4");
+    MI_REQUIRE(e->ctx, !e->pending, "mi_edm_set_kernel_choice: an evaluation is in flight");
+    e->waves_per_real = waves_per_realisation;
+    e->no_uniform_div = uniform_division == 0;
+    return MI_OK;
 }
 
 mi_status mi_edm_compute_f_begin(mi_edm* e, const double* z)
@@ -1125,10 +1168,8 @@ mi_status mi_edm_debug_counters(mi_edm* e, uint64_t out[MI_EDM_N_COUNTERS])
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
     if (err == hipSuccess) {
         const bool hetero = e->p.beta_stddev != 0.0f, three = e->p.n_spikes <= 3;
-        const size_t lds_bytes = ((size_t)kMaxGrid + (size_t)(kEvolveBlock / 64) * (hetero ? 3 : 2) * 64u * (unsigned)__builtin_popcount(live)) * sizeof(float);
-        const unsigned cus = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256);
-        const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
-        const unsigned blocks = std::min<unsigned>((e->p.n_real + 3) / 4, cus * per_cu);
+        const size_t lds_bytes = evolve_lds_bytes(hetero, live);
+        const unsigned blocks = (e->p.n_real + 3) / 4;
 #define MI_TAPPED(MATH, H, NS)                                                                                              \
     hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, false, true>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
                        e->M, e->last_sd, live, d_taps, e->d_v, e->d_s, e->d_w, e->d_t0, e->d_i0, e->d_t1,     \
@@ -1168,6 +1209,7 @@ mi_status mi_edm_math_probe(mi_ctx* ctx, int math_mode, int op, const float* a_d
 {
     MI_REQUIRE(ctx, ctx && a_dev && out_dev, "mi_edm_math_probe: NULL argument");
     if (n == 0) return MI_OK;
+    MI_REQUIRE(ctx, op != 12 || n % 64 == 0, "mi_edm_math_probe: op 12 exchanges lane pairs and needs whole waves (n %% 64 == 0)");
     const unsigned grid = (unsigned)((n + 255) / 256);
     if (math_mode == MI_EDM_MATH_FAST)
         hipLaunchKernelGGL((math_probe_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, op, a_dev, b_dev ? b_dev : a_dev, out_dev, n);

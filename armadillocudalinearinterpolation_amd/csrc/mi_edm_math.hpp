@@ -173,10 +173,9 @@ MI_HD float div_(float a, float b)
 // within 1.5 ulp of a/c; one Newton step q1 = RN(q0 + RN(a - c q0) y) (the residual is exact by fma) is a faithful
 // rounding of a/c, and by Markstein's theorem (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic,
 // sec. 4.7) a second step from a faithful quotient with y = RN(1/c) gives RN(a/c) itself: five multiply/fma.  The
-// theorem wants no overflow and exact (possibly subnormal) residuals: |c| in [2^-20, 2^20] and |a| in [2^-100, 2^100].
-// A zero, infinite or NaN numerator gives its IEEE result already as a * y (signed zero, signed infinity, NaN); a finite
-// numerator outside the range takes the IEEE expansion (the wave skips it when no lane needs it; none did in 5e9
-// divisions of ComputeF at the reference's parameters), and so does a divisor outside its range.
+// theorem wants no overflow and exact (possibly subnormal) residuals: |c| in [2^-20, 2^20] and |a| in [2^-100, 2^101).
+// Every other numerator -- zero, subnormal, tiny, huge, infinite, NaN -- takes the IEEE expansion (the wave skips it when no
+// lane needs it: the guard is a bit-field extract, a subtract and a compare), and so does a divisor outside its range.
 // Checked against `/` bit for bit by tests/test_edm_gpu.py::test_uniform_divisor_quotient_is_the_ieee_quotient.
 // Used where it pays: with eight waves per SIMD (N <= 512, the reference's Driver.cu) Evolve is 13 % faster with it; at
 // N = 1024 (four waves per SIMD) the guard costs what the division saves (profiles/r02_edm_evolve_phases.log).
@@ -188,17 +187,16 @@ MI_HD float div_by(float a, float c)
     if constexpr (UNI) {
         if (fabsf(c) >= 0x1.0p-20f && fabsf(c) <= 0x1.0p+20f) {      // (uniform)
             const float rc = 1.0f / c;
-            const float aa = fabsf(a);
             const float q0 = a * rc;
             float q = fmaf(fmaf(-c, q0, a), rc, q0);
             q = fmaf(fmaf(-c, q, a), rc, q);
-            const bool in_range = aa >= 0x1.0p-100f && aa <= 0x1.0p+100f;   // false for NaN
-            const bool trivial = !(aa > 0.0f) || aa == INFINITY;            // zero, NaN, infinity
-            q = in_range ? q : q0;
-            const bool hard = !in_range && !trivial;
-            if (__any(hard)) {
+            // biased exponent of a in [27, 227], i.e. |a| in [2^-100, 2^101): three integer instructions.  Anything else --
+            // zero, subnormal, tiny, huge, infinite, NaN -- takes the IEEE expansion; the wave skips it when no lane needs it
+            const unsigned ex = (__float_as_uint(a) >> 23) & 0xffu;
+            const bool in_range = (ex - 27u) <= 200u;
+            if (__any(!in_range)) {
                 const float qi = a / c;
-                q = hard ? qi : q;
+                q = in_range ? q : qi;
             }
             return q;
         }
@@ -284,6 +282,59 @@ MI_HD float newton_time(const Model& M, float v0, float s0, float beta, uint32_t
         r = fun_dfun_e<MATH, UNI>(M, expf_<MATH>(-t), expf_<MATH>((1.0f - beta) * t), v0, s0, beta);
         f = r.f;
         df = r.df;
+        ++counter;
+    }
+    if (iters) *iters = counter;
+    return fabsf(t);
+}
+
+// the value x holds in lane (lane ^ 32) of the wave; both lanes of the pair must be active.  upper = lane >= 32.
+// (v_permlane32_swap_b32: one VALU instruction, no LDS round trip)
+__device__ __forceinline__ float other_half(float x, bool upper)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, upper ? r[0] : r[1]);
+#else
+    (void)upper;
+    return x;      // (the host pass only parses the kernels)
+#endif
+}
+
+// newton_time() for a neuron given to the lane PAIR (l, l + 32), both holding the same (v0, s0, beta): the lower lane
+// evaluates exp(-t) and f, the upper lane exp((1 - beta) t) and df, in ONE pass of the exponential and ONE of the
+// division per iteration instead of two each (the rounds run with some ten of 64 lanes busy, so the partner is free),
+// and the halves are exchanged by v_permlane32_swap.  Every operation a lane keeps is the one newton_time performs, on
+// the same operands, so t is the same bit pattern in both lanes and equal to newton_time's: -t is (-1) t; the
+// derivative's quotient a / (beta - 1) is formed as -(a / (1 - beta)), the same number (beta - 1 = -(1 - beta) exactly,
+// and IEEE division is sign-symmetric; only the sign of a NaN can differ, and a NaN time never wins the arg-min).
+template <int MATH, bool UNI = false>
+__device__ __forceinline__ float newton_time_paired(const Model& M, float v0, float s0, float beta, bool upper,
+                                                    uint32_t* iters = nullptr)
+{
+    const float omb = 1.0f - beta;
+    float t = 0.0f;
+    FdF r = fun_dfun_e<MATH, UNI>(M, 1.0f, 1.0f, v0, s0, beta);
+    float f = r.f, df = r.df;
+    const float cx = upper ? omb : -1.0f;
+    uint32_t counter = 0;
+    while ((fabsf(f) > M.tol_f) && (counter < M.max_iter)) {
+        t = t - div_<MATH>(f, df);
+        const float e = expf_<MATH>(cx * t);              // lower: exp(-t); upper: exp((1 - beta) t)
+        const float eo = other_half(e, upper);
+        const float e1 = upper ? eo : e, e2 = upper ? e : eo;
+        const float se = s0 * e1;
+        const float em1 = e2 - 1.0f;
+        float q = div_by<MATH, UNI>(upper ? se * em1 : se, omb);
+        q = upper ? -q : q;
+        const float ve = v0 * e1;
+        const float fv = ((ve + M.I * (1.0f - e1)) + q * em1) - M.vth;     // :546 (meaningful in the lower lane)
+        const float dv = ((M.I * e1 - ve) + se * e2) + q;                  // :551 (meaningful in the upper lane)
+        const float mine = upper ? dv : fv;
+        const float theirs = other_half(mine, upper);
+        f = upper ? theirs : mine;
+        df = upper ? mine : theirs;
         ++counter;
     }
     if (iters) *iters = counter;

@@ -272,6 +272,11 @@ mi_status mi_edm_create(mi_ctx* ctx, const mi_edm_params* p, mi_edm** out);
 mi_status mi_edm_destroy(mi_edm* e);
 /* setters of EventDrivenMap.hpp:27-51 arrive as a new parameter block */
 mi_status mi_edm_set_params(mi_edm* e, const mi_edm_params* p);
+/* Tuning / test knob; every choice gives bit-identical results (tests/test_edm_gpu.py runs each case under all of them).
+ * waves_per_realisation: 0 = by realisation count (default: a workgroup of four waves per realisation below 600
+ * realisations, one wave per realisation from there), 1 or 4 = that form always.  uniform_division: 1 (default) = the
+ * five-operation exact quotient where a divisor is the same for the whole launch, 0 = IEEE division everywhere. */
+mi_status mi_edm_set_kernel_choice(mi_edm* e, int waves_per_realisation, int uniform_division);
 /* ComputeF (EventDrivenMap.cu:154-240).  z: host, n_spikes doubles (c, Z1..);
  * f: host, n_spikes doubles.  partial (optional, may be NULL): host,
  * MI_EDM_PARTIAL_LEN(n_spikes) doubles receiving this device's partial block
@@ -318,8 +323,9 @@ mi_status mi_edm_last_timings(mi_edm* e, float ms[4]);
  * (op: 0 exp, 1 log, 2 pow(a,b), 3 erfinv; 4: a / b[0] the way the kernels divide
  * by a wave-uniform divisor, 5: a / b[0] by IEEE division; 6..11: the firing test
  * will_fire(v0 = a, s0 = b) -> 0/1 on its exact path (even op) and with its hardware
- * pre-decision (odd op) for beta = 13.0589, 1.5, 0.7) so that tests can compare
- * them with oracle/edm_oracle.c bit for bit.  Device pointers; b_dev may be NULL. */
+ * pre-decision (odd op) for beta = 13.0589, 1.5, 0.7; 12: a[i ^ 32], the lane-pair
+ * exchange the paired firing-time solves rely on, n a multiple of 64) so that tests can
+ * compare them with oracle/edm_oracle.c bit for bit.  Device pointers; b_dev may be NULL. */
 mi_status mi_edm_math_probe(mi_ctx* ctx, int math_mode, int op, const float* a_dev, const float* b_dev,
                             float* out_dev, size_t n);
 

@@ -109,6 +109,16 @@ def test_firing_test_pre_decision_never_changes_the_decision(mi_ctx, evolve_form
             assert np.array_equal(_probe(mi_ctx, 0, op_exact, v0, sv), _probe(mi_ctx, 0, op_exact + 1, v0, sv))
 
 
+def test_lane_pair_exchange_of_the_paired_solves(mi_ctx, evolve_form):
+    """edm::other_half (v_permlane32_swap_b32): every lane must receive the value of lane ^ 32 -- the paired firing-time
+    solves (edm::newton_time_paired) exchange their exponentials and f / f' through it."""
+    if evolve_form != "auto":
+        pytest.skip("pure math probe: no evolve kernel involved")
+    a = np.arange(1024, dtype=np.float32) * 0.5 - 3.0
+    out = _probe(mi_ctx, 0, 12, a)
+    assert np.array_equal(out, a[np.arange(1024) ^ 32])
+
+
 def test_uniform_division_path_changes_nothing(mi_ctx, monkeypatch):
     """N = 512 (the reference's Driver.cu grid) takes the exact quotient by uniform divisors in the wave-per-realisation
     kernel; MI_EDM_NO_UNIFORM_DIV switches it off.  Every event array must be the same either way."""
