@@ -26,13 +26,18 @@ def _deps():
     return sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(REPO_ROOT, "include", "*.h"))
 
 
-def source_hash():
+def source_hash(family=None):
     """sha256 over the device / ABI sources the library is built from (sorted paths, contents only): what a committed
-    profile is stamped with, so that bench.py can tell whether a measured traffic figure belongs to the running build."""
+    profile is stamped with, so that bench.py can tell whether a measured traffic figure belongs to the running build.
+    family="interp1": only the sources the 1-D table kernels are compiled from (mi_interp1*, mi_common.hpp, mi_ctx.hip and
+    the ABI header), so that work on another kernel family does not orphan the headline's traffic profile."""
     import hashlib
     h = hashlib.sha256()
     for p in sorted(_deps()):
-        h.update(os.path.basename(p).encode())
+        b = os.path.basename(p)
+        if family == "interp1" and not (b.startswith("mi_interp1") or b in ("mi_common.hpp", "mi_ctx.hip", "mi355_interp.h")):
+            continue
+        h.update(b.encode())
         h.update(open(p, "rb").read())
     return h.hexdigest()
 
@@ -52,6 +57,19 @@ def build_lib(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libmi355interp.so cannot be built (there is no CPU fallback)")
+    # One builder at a time (bench.py --gpus N starts N ranks that all import the package: with a stale library they would
+    # compile into the same object files at once and one could link what another is still writing).  The lock is held for
+    # the whole build; whoever waited finds the library fresh and returns.
+    import fcntl
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    with open(os.path.join(CSRC, "build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not is_stale():
+            return LIB_PATH
+        return _build_locked(hipcc, force, verbose)
+
+
+def _build_locked(hipcc, force, verbose):
     from concurrent.futures import ThreadPoolExecutor
     extra = os.environ.get("MI_EXTRA_HIPCC_FLAGS", "").split()
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + extra + ["-I", os.path.join(REPO_ROOT, "include"), "-I", CSRC]

@@ -128,11 +128,14 @@ class Timer:
         check(self._L.mi_timer_elapsed_ms(self._h, C.byref(ms)), self._ctx._h)
         return float(ms.value)
 
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mi_timer_destroy(self._h)
+            self._h = None
+
     def __del__(self):
         try:
-            if self._h:
-                self._L.mi_timer_destroy(self._h)
-                self._h = None
+            self.close()
         except Exception:
             pass
 
@@ -550,6 +553,9 @@ class _GroupCtx:
     def timer(self):
         """HIP events on this member's stream (the stream its shard's kernels are launched on)"""
         return Timer(self)
+
+    def device_info(self):
+        return Context.device_info(self)
 
 
 class Group:

@@ -101,14 +101,21 @@ def timed_loop(ctx, fn, steps, warmup, barrier):
     return wall, tm.elapsed_ms() * 1e-3
 
 
-def cpu_baseline(X, Y, nq_total):
+def cpu_baseline(X, Y, nq_total, sample=100_000_000, queries="random"):
     """The CPU oracle (kind 'port': the repo's restatement of arma::interp1 semantics, bracket formulation,
-    OpenMP over queries) on a bounded sample of the same workload, on this box's host cores."""
+    OpenMP over queries) on a bounded sample of the same workload, on this box's host cores.  At N = 1 the sample is the
+    whole headline query set; rank 0 of an N > 1 run (whose other ranks wait at a barrier meanwhile) takes 2e7 queries."""
+    import numpy as np
+
     import oracle
     # a 1-GPU box's CPU share is 16 threads (more are visible but belong to other tenants)
     threads = min(oracle.max_threads(), os.cpu_count() or 1, 16)
-    n = min(nq_total, 100_000_000)                                       # the whole headline query set (0.8 GB)
+    n = min(nq_total, sample)
     xi = oracle.splitmix_uniform(SEED_Q, n)
+    if queries == "sorted":
+        xi = np.sort(xi)
+    elif queries == "uniform":
+        xi = np.arange(n, dtype=np.float64) / max(n - 1, 1)
     oracle.interp1_bracket(X, Y, xi[:1_000_000], nthreads=threads)      # warm caches / thread pool
     best = None
     for _ in range(3):
@@ -122,11 +129,35 @@ def cpu_baseline(X, Y, nq_total):
     oracle.interp1_arma(X, Y, xi[:m])
     t_arma = time.perf_counter() - t
     return {"value": n / best, "unit": "points/s", "cores": threads, "kind": "port",
-            "sample": "first %d of the %d SplitMix64 queries (seed 0x5EED0003), same 1e6-node table, "
-                      "oracle.interp1_bracket (OpenMP), best of 3, %.2f s per pass" % (n, nq_total, best),
+            "sample": "first %d of the %d %s queries (SplitMix64 seed 0x5EED0003), same %d-node table, "
+                      "oracle.interp1_bracket (OpenMP), best of 3, %.2f s per pass" % (n, nq_total, queries, len(X), best),
             "arma_interp1_semantics_1thread_points_per_s": m / t_arma,
             "arma_interp1_semantics_sample": "oracle.interp1_arma (sort + resumed scan + un-permute, the literal "
                                              "Armadillo algorithm) on the first %d queries, %.2f s" % (m, t_arma)}
+
+
+def cpu_baseline_config3(n3, nq_total, sample=20_000_000):
+    """CPU oracle (kind 'port') for BASELINE configs[2]: oracle.interp2_bilinear_uniform (OpenMP) on the first `sample`
+    query pairs of the 0x5EED0004 stream over the same 4096 x 4096 table."""
+    import numpy as np
+
+    import oracle
+    threads = min(oracle.max_threads(), os.cpu_count() or 1, 16)
+    n = min(nq_total, sample)
+    q = oracle.splitmix_uniform(0x5EED0004, 2 * n)
+    g = np.arange(n3, dtype=np.float64) / (n3 - 1)
+    z = np.sin(2 * np.pi * g)[:, None] * np.cos(2 * np.pi * g)[None, :] + g[None, :] * g[:, None]     # Z(i,j), SURVEY 8d config 3
+    h = 1.0 / (n3 - 1)
+    oracle.interp2_bilinear_uniform(0.0, h, n3, 0.0, h, n3, z, q[:100_000], q[n:n + 100_000], nthreads=threads)
+    best = None
+    for _ in range(2):
+        t = time.perf_counter()
+        oracle.interp2_bilinear_uniform(0.0, h, n3, 0.0, h, n3, z, q[:n], q[n:], nthreads=threads)
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    return {"value": n / best, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": "first %d of the %d scattered query pairs (SplitMix64 seed 0x5EED0004), same %d x %d table, "
+                      "oracle.interp2_bilinear_uniform (OpenMP), best of 2, %.2f s per pass" % (n, nq_total, n3, n3, best)}
 
 
 def measured_traffic(mode, queries, nq):
@@ -139,9 +170,10 @@ def measured_traffic(mode, queries, nq):
         t = json.load(open(path))
         e = t.get("interp1_mode%d_%s" % (mode, queries))
         if e and int(e.get("nq", 0)) == int(nq):
-            if e.get("source_sha256") != _build.source_hash():
+            if e.get("source_sha256") != _build.source_hash("interp1"):
                 return None, "profiles/traffic_latest.json was measured on another build of the kernels (source hash differs): not quoted", {}
-            l2 = {k: e[k] for k in ("tcc_req_per_launch", "gpu_clock_hz", "l2_request_bound_ms", "tcc_busy_frac") if k in e}
+            l2 = {k: e[k] for k in ("tcc_req_per_launch", "gpu_clock_hz", "l2_request_bound_ms", "tcc_busy_frac",
+                                    "request_cap_per_xcd_per_ns", "request_cap_source") if k in e}
             return e["hbm_bytes_per_launch"], "rocprofv3 PMC passes of this build (scripts/profile_bench.sh), profiles/traffic_latest.json", l2
     except (OSError, ValueError, KeyError):
         pass
@@ -209,7 +241,8 @@ def bench_config3(args, ctx, info, dev, world, rank, barrier, dist, dist_on):
                          "frac": alg / ks / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": "interp2_order_kernel + interp2_blocks_kernel + interp2_unsort_kernel" if ordered else "interp2_kernel",
                          "kernel_ms": ks * 1e3, "algorithmic_bytes_per_launch": alg},
-            "cpu_baseline": None, "device": info["name"]}), flush=True)
+            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_config3(n3, nq),
+            "device": info["name"]}), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
@@ -281,7 +314,9 @@ def bench_group(args):
     grp.synchronize()
     wall = time.perf_counter() - t0
     ev = max(tm.elapsed_ms() for tm in timers) * 1e-3
-    info = mi.Context(devices[0]).device_info()
+    for tm in timers:
+        tm.close()
+    info = grp.ctx(0).device_info()
     table_bytes = 8.0 * (args.ng + 1)
     alg = 16.0 * nq + table_bytes
     ks = ev / args.steps
@@ -301,7 +336,8 @@ def bench_group(args):
                      "kernel": "per device: the kernel mi_interp1_f64_dev picks for its shard",
                      "kernel_ms": ks * 1e3, "algorithmic_bytes_per_launch": alg,
                      "note": "slowest device's HIP-event time per step (events on each member's own stream)"},
-        "cpu_baseline": None, "device": info["name"]}), flush=True)
+        "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(X, Y, nq, sample=100_000_000 if n == 1 else 20_000_000),
+        "device": info["name"]}), flush=True)
     tab.close()
     grp.close()
     return 0
@@ -434,9 +470,11 @@ def main():
         result["roofline"]["l2_request_bound_ms"] = l2["l2_request_bound_ms"]
         result["roofline"]["l2_request_frac"] = l2["l2_request_bound_ms"] / (kernel_s * 1e3)
         result["roofline"]["l2_requests_per_launch"] = l2["tcc_req_per_launch"]
-        # the same requests at the rate the XCDs' vector request paths were MEASURED to sustain (33 per ns per XCD with all CUs
-        # gathering from an L2-resident table, profiles/r03_exp_gather_rate_vs_active_cus.log): the floor of this algorithm
-        result["roofline"]["request_floor_ms_at_measured_cap"] = l2["tcc_req_per_launch"] / (8 * 33.0e9) * 1e3
+        # the same requests at the rate the XCDs' vector request paths were MEASURED to sustain with all CUs gathering from an
+        # L2-resident table (the stamped profile names the figure and the log it comes from): the floor of this algorithm
+        if l2.get("request_cap_per_xcd_per_ns"):
+            result["roofline"]["request_floor_ms_at_measured_cap"] = l2["tcc_req_per_launch"] / (8 * l2["request_cap_per_xcd_per_ns"] * 1e9) * 1e3
+            result["roofline"]["request_cap_source"] = l2.get("request_cap_source")
         result["roofline"]["l2_note"] = ("TCC_REQ per launch / (128 L2 channels x %.2f GHz measured clock): the time the XCD L2s need "
                                          "for the launch's requests at one per channel-clock; profiled TCC_BUSY fraction %.2f"
                                          % (l2["gpu_clock_hz"] * 1e-9, l2.get("tcc_busy_frac") or float("nan")))
@@ -450,10 +488,13 @@ def main():
             return e / reps
 
         xs = torch.sort(xq).values
+        xu = torch.arange(nq, dtype=torch.float64, device=dev) / max(nq - 1, 1)          # the uniform set XI_j = j/(NQ-1)
         gu = mi.Grid1.uniform(ctx, 0.0, 1.0 / (args.ng - 1), Y)
-        for name, g, q in (("general_sorted", grid, xs), ("uniform_random", gu, xq), ("uniform_sorted", gu, xs)):
+        for name, g, q in (("general_sorted", grid, xs), ("general_uniformq", grid, xu), ("uniform_random", gu, xq),
+                           ("uniform_sorted", gu, xs)):
             s = quick(lambda: g.interp(q, out=yq))
             extra[name] = {"ms": s * 1e3, "points_per_s": nq / s, "frac_of_8TBps": 16.0 * nq / s / 1e9 / HBM_PEAK_GBPS}
+        del xu
         # BASELINE.md section 2's non-uniform variant: X_i = (i + 0.5 u_i)/NG (seed 0x5EED0002), explicit {x,y} table
         un = synth.splitmix_uniform(0x5EED0002, args.ng, torch.device("cpu")).numpy()
         Xn = (np.arange(args.ng) + 0.5 * un) / args.ng
@@ -551,11 +592,22 @@ def main():
         extra["allgather_ms"] = (time.perf_counter() - t) * 1e3
         extra["allgather_note"] = "RCCL all-gather of %d x 8e8 B result shards, outside the timed region" % world
         del full
+    if dist_on and world > 1:
+        # a reader of ONE file should be able to form the 1 -> N ratio: after the timed region rank 0 repeats the very same
+        # step alone (the other ranks wait at the barrier below, their GPUs idle) -- the N = 1 time of this shard size
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:
+            w1, e1 = timed_loop(ctx, lambda: grid.interp(xq, out=yq), args.steps, args.warmup, lambda: None)
+            extra["n1_reference_ms"] = w1 / args.steps * 1e3
+            extra["n1_reference_note"] = ("rank 0 alone, same %d-query shard, %d steps, the other %d ranks idle at a barrier: "
+                                          "ms_per_step / n1_reference_ms is the slow-down of one shard when all %d GPUs run"
+                                          % (nq, args.steps, world - 1, world))
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(X, Y, nq)
-        else:
-            result["cpu_baseline"] = None
+        # the CPU baseline beside EVERY line (north_star: "reported at 1, 2, 4 and 8 GPUs alongside that CPU baseline"): the
+        # whole 1e8-query set at N = 1, a 2e7-query sample at N > 1 (the other ranks wait at the closing barrier meanwhile)
+        result["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(
+            X, Y, nq, sample=100_000_000 if world == 1 else 20_000_000, queries=args.queries)
         result["extra"] = extra
         if extra_strong:
             result["strong_scaling"] = extra_strong

@@ -121,6 +121,10 @@ def main():
         l2 = {"tcc_req_per_launch": req, "gpu_clock_hz": clk, "l2_channels": 128,
               "l2_request_bound_ms": req / (128.0 * clk) * 1e3,
               "tcc_busy_frac": (pm[dom]["TCC_BUSY_sum"]["per_dispatch_median"] / (128.0 * clk * dur_us * 1e-6)) if "TCC_BUSY_sum" in pm[dom] else None}
+        # the rate an XCD's vector request path was measured to sustain (not re-measured here: the experiment's own log)
+        l2["request_cap_per_xcd_per_ns"] = 33.0
+        l2["request_cap_source"] = ("profiles/r03_exp_gather_rate_vs_active_cus.log: all 32 CUs of an XCD gathering from an "
+                                    "L2-resident 2 MiB table, 1.03 distinct lines per ns per CU")
         summary["l2_request_roofline"] = {dom: l2}
         for e in latest.values():
             if e["kernel"] == dom:
@@ -136,7 +140,7 @@ def main():
         try:
             sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
             from armadillocudalinearinterpolation_amd import _build
-            stamp = _build.source_hash()
+            stamp = _build.source_hash("interp1")
         except Exception:
             stamp = None
         for e in latest.values():

@@ -40,12 +40,17 @@ def test_plain_multi_gpu_invocation_starts_a_launcher_child_and_relays_its_exit_
 def test_plain_gpus_2_self_launches_two_ranks_and_prints_one_line():
     """`python3 bench.py --gpus 2 ...` with no launcher around it: two rank processes (gloo rendezvous on 127.0.0.1, both
     on cuda:0 -- a rehearsal, timings meaningless) and ONE JSON line, the last line of stdout, with n_gpus = 2."""
-    out = _run("--gpus", "2", "--dist-backend", "gloo", "--rehearse-one-device", *SMALL)
+    out = _run("--gpus", "2", "--dist-backend", "gloo", "--rehearse-one-device", "--nq", "2000000", "--steps", "2", "--warmup", "1",
+               "--no-extra")
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     r = _last_json(out)
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["scaling"] == "weak"
     assert r["value"] > 0 and r["config"]["queries_per_gpu"] == 2_000_000
     assert sum(1 for ln in out.stdout.splitlines() if '"metric"' in ln) == 1
+    # every N > 1 line carries the CPU baseline (north_star: "reported at 1, 2, 4 and 8 GPUs alongside that CPU baseline")
+    # and the one-rank time of the same shard, so that the 1 -> N ratio can be formed from this one line
+    assert r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["cores"] >= 1
+    assert r["extra"]["n1_reference_ms"] > 0
 
 
 @pytest.mark.gpu
@@ -57,6 +62,9 @@ def test_group_backend_reports_the_rccl_communicator_size():
     r = _last_json(out)
     assert r["backend"] == "group" and r["n_gpus"] == 1 and r["rccl_ranks"] == 1
     assert r["config"]["entry_point"].startswith("mi_group_interp1_f64_dev") and r["value"] > 0
+    out = _run("--backend", "group", "--gpus", "1", "--nq", "2000000", "--steps", "2", "--warmup", "1")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert _last_json(out)["cpu_baseline"]["value"] > 0                    # the group line carries the CPU baseline too
     # the all-gather form on the same communicator
     out = _run("--backend", "group", "--gpus", "1", "--gather", *SMALL)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
@@ -72,3 +80,14 @@ def test_group_backend_rehearsal_with_a_repeated_device():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     r = _last_json(out)
     assert r["n_gpus"] == 3 and r["rccl_ranks"] == 0 and r["config"]["devices"] == [0, 0, 0]
+
+
+@pytest.mark.gpu
+def test_config3_line_carries_roofline_and_cpu_baseline():
+    """--config 3 (BASELINE configs[2]) at a small query count: one line, roofline of interp2_kernel, CPU baseline from the
+    bilinear oracle on the same 4096 x 4096 table."""
+    out = _run("--config", "3", "--nq", "2000000", "--steps", "2", "--warmup", "1", timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    r = _last_json(out)
+    assert r["roofline"]["kernel"] == "interp2_kernel" and r["roofline"]["frac"] > 0
+    assert r["cpu_baseline"]["value"] > 0 and "interp2_bilinear_uniform" in r["cpu_baseline"]["sample"]
