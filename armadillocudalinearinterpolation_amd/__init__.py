@@ -6,6 +6,6 @@ Importing this package does not touch the GPU; the first Context() does.
 """
 from ._lib import MiError, lib_path, load  # noqa: F401
 from .api import (  # noqa: F401
-    INTERP2_AUTO, INTERP2_DIRECT, INTERP2_ORDERED, MATH_EXACT, MATH_FAST, Context, EventDrivenMap, Grid1, Grid2, Group, Timer, default_edm_params, interp1,
+    MATH_EXACT, MATH_FAST, Context, EventDrivenMap, Grid1, Grid2, Group, Timer, default_edm_params, interp1,
     masked_mean, restrict, restrict_mean, shard_bounds,
 )

@@ -55,7 +55,6 @@ SIGNATURES = {
     "mi_ctx_own_stream": (_i32, [_vp]),
     "mi_ctx_synchronize": (_i32, [_vp]),
     "mi_ctx_set_query_order": (_i32, [_vp, _i32]),
-    "mi_ctx_set_interp2_path": (_i32, [_vp, _i32]),
     "mi_ctx_device_info": (_i32, [_vp, C.c_char_p, _sz, C.POINTER(_i32), C.POINTER(_sz)]),
     "mi_timer_create": (_i32, [_vp, _pp]),
     "mi_timer_destroy": (_i32, [_vp]),
@@ -72,8 +71,7 @@ SIGNATURES = {
     "mi_grid2_create": (_i32, [_vp, _vp, _sz, _vp, _sz, _vp, C.c_uint, _pp]),
     "mi_grid2_create_uniform": (_i32, [_vp, _dbl, _dbl, _sz, _dbl, _dbl, _sz, _vp, C.c_uint, _pp]),
     "mi_grid2_destroy": (_i32, [_vp]),
-    "mi_grid2_reserve": (_i32, [_vp, _vp, _sz]),
-    "mi_grid2_info": (_i32, [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i32)]),
+    "mi_grid2_info": (_i32, [_vp, C.POINTER(_sz)]),
     "mi_interp2_f64_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _dbl]),
     "mi_interp2_f64_host": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _dbl]),
     "mi_restrict_f32_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _vp, _sz]),
@@ -152,8 +150,8 @@ def load(build_if_missing=True, strict=True):
         fn.argtypes = args
     if missing and strict:
         raise RuntimeError("libmi355interp.so lacks symbols declared in mi355_interp.h: %s" % ", ".join(missing))
-    if L.mi_abi_version() != 3:
-        raise RuntimeError("libmi355interp.so ABI version %d != 3" % L.mi_abi_version())
+    if L.mi_abi_version() != 4:
+        raise RuntimeError("libmi355interp.so ABI version %d != 4" % L.mi_abi_version())
     _lib = L
     return L
 

@@ -20,7 +20,6 @@ from ._lib import EdmParams, MiError, check  # noqa: F401
 MI_GRID_SANITISE = 0x1
 MI_GRID_DEVICE_PTRS = 0x2
 MI_GRID2_COMPACT = 0x4
-INTERP2_AUTO, INTERP2_DIRECT, INTERP2_ORDERED = 0, 1, 2
 MATH_EXACT = 0
 MATH_FAST = 1
 
@@ -71,10 +70,6 @@ class Context:
 
     def synchronize(self):
         check(self._L.mi_ctx_synchronize(self._h), self._h)
-
-    def set_interp2_path(self, path):
-        """INTERP2_AUTO / INTERP2_DIRECT / INTERP2_ORDERED (mi_ctx_set_interp2_path)"""
-        check(self._L.mi_ctx_set_interp2_path(self._h, int(path)), self._h)
 
     def set_query_order(self, order):
         """0 auto (device-side probe), 1 queries are unordered, 2 queries are ordered/clustered."""
@@ -267,15 +262,10 @@ class Grid2:
                                              _ptr(zc), flags, C.byref(h)), ctx._h)
         return cls(ctx, h)
 
-    def reserve(self, max_queries):
-        """size the workspace of the call-wide cell ordering (mi_grid2_reserve; 0 frees it -> direct kernel only)"""
-        check(self._L.mi_grid2_reserve(self._ctx._h, self._h, int(max_queries)), self._ctx._h)
-        return self
-
     def info(self):
-        tb, wq, nb = C.c_size_t(0), C.c_size_t(0), C.c_int(0)
-        check(self._L.mi_grid2_info(self._h, C.byref(tb), C.byref(wq), C.byref(nb)))
-        return {"table_bytes": tb.value, "workspace_queries": wq.value, "ordered_blocks": nb.value}
+        tb = C.c_size_t(0)
+        check(self._L.mi_grid2_info(self._h, C.byref(tb)))
+        return {"table_bytes": tb.value}
 
     def interp(self, xq, yq, out=None, extrap=math.nan):
         torch = _torch()

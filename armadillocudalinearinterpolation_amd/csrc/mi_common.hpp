@@ -28,7 +28,6 @@ struct mi_ctx {
     // three ints inside the workspace: constant 0, constant 1, and the query-order probe's verdict
     static constexpr size_t kFlagOffset = 176 * 1024;
     int query_order = 0;         // MI_QUERIES_AUTO / _RANDOM / _ORDERED (mi_ctx_set_query_order)
-    int interp2_path = 0;        // MI_INTERP2_AUTO / _DIRECT / _ORDERED (mi_ctx_set_interp2_path)
     // MI_QUERIES_AUTO: the probe kernel also drops its verdict into a pinned host int (never waited for); the host
     // reads whatever is there at the next call and uses it only to PREDICT which kernel to launch -- either kernel
     // is correct on any input.  -1 = no verdict yet (both kernels are launched, gated on the device-side flag).

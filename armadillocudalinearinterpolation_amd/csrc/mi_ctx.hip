@@ -160,15 +160,6 @@ mi_status mi_ctx_set_query_order(mi_ctx* ctx, int order)
     return MI_OK;
 }
 
-mi_status mi_ctx_set_interp2_path(mi_ctx* ctx, int path)
-{
-    MI_REQUIRE(ctx, ctx != nullptr, "mi_ctx_set_interp2_path: ctx is NULL");
-    MI_REQUIRE(ctx, path == MI_INTERP2_AUTO || path == MI_INTERP2_DIRECT || path == MI_INTERP2_ORDERED,
-               "mi_ctx_set_interp2_path: unknown value %d", path);
-    ctx->interp2_path = path;
-    return MI_OK;
-}
-
 mi_status mi_ctx_destroy(mi_ctx* ctx)
 {
     if (!ctx) return MI_OK;

@@ -44,12 +44,6 @@ struct mi_grid2 {
     void* dev_y;
     void* dev_z;
     G2Dev d;
-    // call-wide cell ordering (mi_interp2_ordered.hpp): workspace owned by the grid, so that mi_interp2_f64_dev never allocates
-    void* ws = nullptr;
-    size_t ws_bytes = 0;
-    size_t ws_queries = 0;     // capacity in queries (multiple of the tile), 0: no workspace -> the direct kernel only
-    size_t ws_off_stride = 0;  // tiles per row of the block-offset table
-    int ord_sx = 0, ord_sy = 0, ord_nbx = 0, ord_nby = 0;   // block geometry (0 blocks: the ordered path does not apply)
     size_t table_bytes = 0;
 };
 
@@ -165,99 +159,14 @@ __global__ __launch_bounds__(kBlock) void interp2_kernel(G2Dev g, const double* 
 
 }  // namespace mi_interp2
 
-#include "mi_interp2_ordered.hpp"
-
 using namespace mi_interp2;
 
 namespace {
 
-// ---- call-wide cell ordering: geometry, workspace, dispatch ---------------------------------------------------
-// Blocks of at most 2 MiB of resident cells (half of an XCD's 4 MiB L2, the other half is left to the streams), at
-// most kOrdMaxBlocks of them; both axes need the linear coarse index (implicit axes, or explicit ones that stay within a
-// few nodes of a line).
-constexpr size_t kOrdBlockBytes = (size_t)2 << 20;
-constexpr size_t kOrdBytesPerQuery = 16 + 8 + 2;
-
-void ordered_geometry(mi_grid2* g)
+// resident bytes of the table (mi_grid2_info)
+void table_size(mi_grid2* g)
 {
-    g->ord_nbx = g->ord_nby = 0;
-    const AxisDev &ax = g->d.ax, &ay = g->d.ay;
-    const bool linear_x = !ax.nodes || ax.use_guess, linear_y = !ay.nodes || ay.use_guess;
-    const size_t cell_bytes = g->d.quads ? 32 : 16;
-    g->table_bytes = (size_t)ax.n * (size_t)ay.n * cell_bytes;
-    if (!linear_x || !linear_y) return;
-    // cells per block <= 2 MiB / cell_bytes; whole column segments first (ly is the fast index of the layout)
-    size_t cells = kOrdBlockBytes / cell_bytes;
-    int sy = 0, sx = 0;
-    while (((size_t)1 << sy) < (size_t)ay.n && ((size_t)1 << (sy + 1)) <= cells) ++sy;
-    while (((size_t)1 << (sx + sy + 1)) <= cells && ((size_t)1 << sx) < (size_t)ax.n) ++sx;
-    auto nblk = [&](int n, int sh) { return (int)(((size_t)n + ((size_t)1 << sh) - 1) >> sh); };
-    // more than kOrdMaxBlocks blocks (tables beyond 2 GiB): larger blocks (they then overflow L2 in part)
-    while ((size_t)nblk(ax.n, sx) * (size_t)nblk(ay.n, sy) > (size_t)kOrdMaxBlocks) {
-        if (((size_t)1 << sy) < (size_t)ay.n) ++sy; else ++sx;
-    }
-    g->ord_sx = sx;
-    g->ord_sy = sy;
-    g->ord_nbx = nblk(ax.n, sx);
-    g->ord_nby = nblk(ay.n, sy);
-}
-
-mi_status reserve_workspace(mi_ctx* ctx, mi_grid2* g, size_t max_queries)
-{
-    if (g->ws) {
-        MI_HIP(ctx, hipStreamSynchronize(ctx->stream));   // a call in flight may still use it
-        (void)hipFree(g->ws);
-        g->ws = nullptr;
-        g->ws_queries = 0;
-    }
-    if (max_queries == 0 || g->ord_nbx == 0) return MI_OK;
-    // positions inside the workspace are 32-bit: at most 2^31 queries per pass (56 GB); a longer call runs several passes
-    max_queries = std::min<size_t>(max_queries, (size_t)1 << 31);
-    const size_t tiles = (max_queries + kOrdTile - 1) / kOrdTile;
-    const size_t cap = tiles * kOrdTile;
-    const size_t stride = (tiles + 63) & ~(size_t)63;
-    const size_t nb = (size_t)g->ord_nbx * g->ord_nby;
-    const size_t bytes = ((cap * kOrdBytesPerQuery + (nb + 1) * stride * sizeof(unsigned short) + 63) & ~(size_t)63) + 64;   // + queue heads
-    hipError_t e = hipMalloc(&g->ws, bytes);
-    if (e != hipSuccess) {
-        g->ws = nullptr;
-        return mi::fail(ctx, MI_ERR_NOMEM, "mi_grid2: workspace of %zu bytes for %zu queries: %s", bytes, cap, hipGetErrorString(e));
-    }
-    g->ws_queries = cap;
-    g->ws_bytes = bytes;
-    g->ws_off_stride = stride;
-    return MI_OK;
-}
-
-// one pass of the ordered path over n <= ws_queries queries (n a multiple of kOrdTile)
-mi_status launch_ordered(mi_ctx* ctx, const mi_grid2* g, const double* xq, const double* yq, double* zq, size_t n, double extrap)
-{
-    const size_t ntiles = n / kOrdTile;
-    char* w = static_cast<char*>(g->ws);
-    d2* ws_xy = reinterpret_cast<d2*>(w);
-    double* ws_z = reinterpret_cast<double*>(w + g->ws_queries * 16);
-    unsigned* ws_sp2 = reinterpret_cast<unsigned*>(w + g->ws_queries * 24);
-    unsigned short* ws_off = reinterpret_cast<unsigned short*>(w + g->ws_queries * 26);
-    unsigned* queues = reinterpret_cast<unsigned*>(w + g->ws_bytes - 64);   // eight work-queue heads of pass 2
-    OrdGeom o{g->ord_sx, g->ord_sy, g->ord_nbx, g->ord_nby, g->ord_nbx * g->ord_nby};
-    const unsigned cus = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256);
-    const unsigned g1 = (unsigned)std::min<size_t>(ntiles, (size_t)cus * 2);        // two 66-KiB workgroups per CU
-    hipLaunchKernelGGL(interp2_order_kernel, dim3(g1), dim3(kOrdThreads), 0, ctx->stream, g->d, o, xq, yq, ntiles, ws_xy,
-                       ws_sp2, ws_off, g->ws_off_stride, queues);
-    MI_LAUNCH_CHECK(ctx, "interp2 ordering kernel");
-    const unsigned g2 = cus * 8;                                                    // resident at once: 8 x 256 lanes per CU
-    const bool implicit_axes = !g->d.ax.nodes && !g->d.ay.nodes;
-    if (implicit_axes)
-        hipLaunchKernelGGL(interp2_blocks_kernel<true>, dim3(g2), dim3(kOrdEvalThreads), 0, ctx->stream, g->d, o, ntiles,
-                           (const d2*)ws_xy, ws_z, (const unsigned short*)ws_off, g->ws_off_stride, extrap, queues);
-    else
-    hipLaunchKernelGGL(interp2_blocks_kernel<false>, dim3(g2), dim3(kOrdEvalThreads), 0, ctx->stream, g->d, o, ntiles,
-                       (const d2*)ws_xy, ws_z, (const unsigned short*)ws_off, g->ws_off_stride, extrap, queues);
-    MI_LAUNCH_CHECK(ctx, "interp2 block-evaluation kernel");
-    hipLaunchKernelGGL(interp2_unsort_kernel, dim3((unsigned)ntiles), dim3(kOrdEvalThreads), 0, ctx->stream,
-                       (const double*)ws_z, (const unsigned*)ws_sp2, zq);
-    MI_LAUNCH_CHECK(ctx, "interp2 un-ordering kernel");
-    return MI_OK;
+    g->table_bytes = (size_t)g->d.ax.n * (size_t)g->d.ay.n * (g->d.quads ? 32 : 16);
 }
 
 mi_status to_host(mi_ctx* ctx, const double* p, size_t n, bool dev, std::vector<double>& v)
@@ -397,7 +306,6 @@ void destroy(mi_grid2* g)
     if (g->dev_x) (void)hipFree(g->dev_x);
     if (g->dev_y) (void)hipFree(g->dev_y);
     if (g->dev_z) (void)hipFree(g->dev_z);
-    if (g->ws) (void)hipFree(g->ws);
     delete g;
 }
 
@@ -432,7 +340,7 @@ mi_status mi_grid2_create(mi_ctx* ctx, const double* x, size_t nx, const double*
     g->d.quads = quads;
     if (st != MI_OK) { destroy(g); return st; }
     g->d.zp = (const d2v*)g->dev_z;
-    ordered_geometry(g);
+    table_size(g);
     *out = g;
     return MI_OK;
 }
@@ -458,7 +366,7 @@ mi_status mi_grid2_create_uniform(mi_ctx* ctx, double x0, double dx, size_t nx, 
     g->d.quads = quads;
     if (st != MI_OK) { destroy(g); return st; }
     g->d.zp = (const d2v*)g->dev_z;
-    ordered_geometry(g);
+    table_size(g);
     *out = g;
     return MI_OK;
 }
@@ -470,19 +378,10 @@ mi_status mi_grid2_destroy(mi_grid2* g)
     return MI_OK;
 }
 
-mi_status mi_grid2_reserve(mi_ctx* ctx, mi_grid2* g, size_t max_queries)
-{
-    MI_REQUIRE(ctx, ctx && g, "mi_grid2_reserve: NULL context or grid");
-    MI_HIP(ctx, hipSetDevice(g->device));
-    return reserve_workspace(ctx, g, max_queries);
-}
-
-mi_status mi_grid2_info(const mi_grid2* g, size_t* table_bytes, size_t* workspace_queries, int* ordered_blocks)
+mi_status mi_grid2_info(const mi_grid2* g, size_t* table_bytes)
 {
     MI_REQUIRE(nullptr, g != nullptr, "mi_grid2_info: grid is NULL");
     if (table_bytes) *table_bytes = g->table_bytes;
-    if (workspace_queries) *workspace_queries = g->ws_queries;
-    if (ordered_blocks) *ordered_blocks = g->ord_nbx * g->ord_nby;
     return MI_OK;
 }
 
@@ -496,17 +395,6 @@ mi_status mi_interp2_f64_dev(mi_ctx* ctx, const mi_grid2* g, const double* xq, c
     MI_REQUIRE(ctx, (a & 7u) == 0, "mi_interp2_f64_dev: pointers must be 8-byte aligned");
     MI_HIP(ctx, hipSetDevice(ctx->device));   // a process may hold contexts on several devices (mi_group)
     const bool vec = (a & 15u) == 0;
-    if (vec && g->ws_queries && ctx->interp2_path == MI_INTERP2_ORDERED && nq >= (size_t)kOrdTile) {
-        // call-wide cell ordering (opt-in: measured SLOWER than the direct kernel on MI355X, see mi_interp2_ordered.hpp), one
-        // pass per workspace-full of queries; the ragged tail (< one tile) goes to the direct kernel
-        while (nq >= (size_t)kOrdTile) {
-            const size_t n = std::min(nq, g->ws_queries) / kOrdTile * kOrdTile;
-            const mi_status st = launch_ordered(ctx, g, xq, yq, zq, n, extrap);
-            if (st != MI_OK) return st;
-            xq += n; yq += n; zq += n; nq -= n;
-        }
-        if (nq == 0) return MI_OK;
-    }
     const size_t lanes = vec ? (nq >> 1) + (nq & 1) : nq;
     const size_t grid = (lanes + kBlock - 1) / kBlock;
     if (grid > 0x7fffffffull) return mi::fail(ctx, MI_ERR_INVALID_ARG, "mi_interp2_f64_dev: nq=%zu too large for one launch", nq);

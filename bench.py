@@ -71,9 +71,6 @@ def parse():
     ap.add_argument("--gather", action="store_true",
                     help="--backend group: also reassemble the whole result vector on every GPU inside the timed step "
                          "(gathered_dev of mi_group_interp1_f64_dev: an RCCL all-gather over xGMI behind the kernels)")
-    ap.add_argument("--interp2-path", choices=["auto", "direct", "ordered"], default="auto",
-                    help="--config 3: auto / direct (one random quad cell per query) or ordered (the call-wide cell ordering through a "
-                         "reserved workspace: measured slower, kept as an alternative)")
     ap.add_argument("--config", type=int, choices=[2, 3], default=2,
                     help="2 (default): BASELINE configs[1], the 1-D headline; 3: configs[2], 4096^2 bilinear, 1e8 scattered "
                          "queries as the timed workload (for profiling interp2_kernel; same JSON contract)")
@@ -201,11 +198,6 @@ def bench_config3(args, ctx, info, dev, world, rank, barrier, dist, dist_on):
     n3, nq = 4096, args.nq
     compact = bool(int(os.environ.get("MI_BENCH_GRID2_COMPACT", "0")))
     g2 = mi.Grid2.uniform(ctx, 0.0, 1.0 / (n3 - 1), n3, 0.0, 1.0 / (n3 - 1), n3, synth.config3_table(n3, dev), compact=compact)
-    ctx.set_interp2_path({"auto": mi.INTERP2_AUTO, "direct": mi.INTERP2_DIRECT, "ordered": mi.INTERP2_ORDERED}[args.interp2_path])
-    if args.interp2_path == "ordered":
-        g2.reserve(nq)
-    g2info = g2.info()
-    ordered = args.interp2_path == "ordered" and g2info["workspace_queries"] > 0
     strong = args.scaling == "strong" or args.shard_of > 0
     if strong:      # ONE set of args.nq query pairs (x = stream[0:NQ], y = stream[NQ:2NQ]), contiguous shard per rank
         from armadillocudalinearinterpolation_amd import sharding
@@ -234,12 +226,10 @@ def bench_config3(args, ctx, info, dev, world, rank, barrier, dist, dist_on):
             "config": {"workload": "2D bilinear interp, 4096x4096 grid, %.0e scattered query points (BASELINE configs[2])" % nq,
                        "queries_per_gpu": nq, "table_layout": "column pairs (2x input bytes)" if compact else "quad cells (4x input bytes)",
                        "entry_point": "mi_interp2_f64_dev",
-                       "path": ("call-wide cell ordering: interp2_order_kernel + interp2_blocks_kernel + interp2_unsort_kernel, "
-                                "%d table blocks, workspace for %d queries" % (g2info["ordered_blocks"], g2info["workspace_queries"]))
-                               if ordered else "direct: interp2_kernel, one random cell per query"},
+                       "path": "interp2_kernel, one random cell per query"},
             "roofline": {"bound": "hbm", "achieved": alg / ks / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": alg / ks / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "interp2_order_kernel + interp2_blocks_kernel + interp2_unsort_kernel" if ordered else "interp2_kernel",
+                         "kernel": "interp2_kernel",
                          "kernel_ms": ks * 1e3, "algorithmic_bytes_per_launch": alg},
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_config3(n3, nq),
             "device": info["name"]}), flush=True)

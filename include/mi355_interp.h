@@ -44,8 +44,13 @@ extern "C" {
 #endif
 
 /* 3 (round 3): + mi_group_rccl_ranks, mi_ctx_set_interp2_path, mi_grid2_reserve, mi_grid2_info;
- *              - mi_debug_sweep_timing (the sweep's phase stamps live in scripts/ harnesses now) */
-#define MI355_INTERP_ABI_VERSION 3
+ *              - mi_debug_sweep_timing (the sweep's phase stamps live in scripts/ harnesses now)
+ * 4 (round 4): - mi_ctx_set_interp2_path, mi_grid2_reserve, MI_INTERP2_* (the call-wide cell ordering of the bilinear path
+ *                was bit-identical and 24 % slower than the direct kernel; it is a recorded experiment now,
+ *                scripts/exp_interp2_ordered.hpp, profiles/r03_config3_ordered_*); mi_grid2_info reports the table size only;
+ *              + mi_edm_set_kernel_choice (replaces two environment hooks), mi_edm_debug_counters,
+ *                mi_group_set_gather_chunks */
+#define MI355_INTERP_ABI_VERSION 4
 
 typedef int mi_status;
 enum {
@@ -90,17 +95,6 @@ size_t mi_debug_pinned_ranges(void);
 #define MI_QUERIES_RANDOM  1
 #define MI_QUERIES_ORDERED 2
 mi_status mi_ctx_set_query_order(mi_ctx* ctx, int order);
-/* Which kernels mi_interp2_f64_dev uses on this context.  AUTO and DIRECT: the direct gather kernel (one random cell
- * per query).  ORDERED: the call-wide cell ordering -- three passes through the grid's workspace (mi_grid2_reserve) that
- * order the queries of the whole call by table block, so that every block is fetched into one XCD's L2 once -- from one
- * tile (4096 queries) up, wherever the grid has a workspace.  It moves 9.6 GB instead of 15.1 GB per 1e8 queries on the
- * 4096^2 table and is nevertheless SLOWER on MI355X (2.55 ms against 2.06 ms: its block pass issues four poorly
- * coalesced vector-memory requests per query and a CU takes about one such request per ns), so AUTO
- * does not take it; it stays as a tested, bit-identical alternative.  Results are bit-identical on every path. */
-#define MI_INTERP2_AUTO    0
-#define MI_INTERP2_DIRECT  1
-#define MI_INTERP2_ORDERED 2
-mi_status mi_ctx_set_interp2_path(mi_ctx* ctx, int path);
 /* name / CU count of the context's device (for bench reports) */
 mi_status mi_ctx_device_info(mi_ctx* ctx, char* name, size_t name_len, int* compute_units,
                              size_t* hbm_bytes);
@@ -173,15 +167,8 @@ mi_status mi_grid2_create(mi_ctx* ctx, const double* x, size_t nx, const double*
 mi_status mi_grid2_create_uniform(mi_ctx* ctx, double x0, double dx, size_t nx, double y0, double dy,
                                   size_t ny, const double* z, unsigned flags, mi_grid2** out);
 mi_status mi_grid2_destroy(mi_grid2* g);
-/* Workspace of the call-wide cell ordering (MI_INTERP2_ORDERED; 26 bytes per query + a small offset table), owned by the
- * grid so that mi_interp2_f64_dev allocates nothing.  No grid has one until this call sizes it; max_queries = 0 frees it.
- * A call with more queries than the workspace holds runs several passes.  Needs axes with a linear coarse index (uniform
- * axes, or explicit ones within a few nodes of a straight line); on other grids the call succeeds and reserves nothing.
- * The workspace is per grid: calls on ONE grid must be ordered on one stream (the reference's objects are not re-entrant
- * either). */
-mi_status mi_grid2_reserve(mi_ctx* ctx, mi_grid2* g, size_t max_queries);
-/* resident table bytes, workspace capacity in queries (0: none), number of table blocks of the ordering (0: n/a) */
-mi_status mi_grid2_info(const mi_grid2* g, size_t* table_bytes, size_t* workspace_queries, int* ordered_blocks);
+/* resident bytes of the table */
+mi_status mi_grid2_info(const mi_grid2* g, size_t* table_bytes);
 mi_status mi_interp2_f64_dev(mi_ctx* ctx, const mi_grid2* g, const double* xq_dev,
                              const double* yq_dev, double* zq_dev, size_t nq, double extrap_val);
 mi_status mi_interp2_f64_host(mi_ctx* ctx, const mi_grid2* g, const double* xq, const double* yq,

@@ -1,3 +1,12 @@
+// RECORDED EXPERIMENT, not product code (moved out of csrc/ in round 4; last product form: commit 6d0f3e1 and before,
+// where csrc/mi_interp2.hip included this file and include/mi355_interp.h exported mi_grid2_reserve /
+// mi_ctx_set_interp2_path).  The call-wide cell ordering below was bit-identical to the direct bilinear kernel on every
+// test and fuzz case (tests/test_interp_gpu.py::test_ordered_bilinear_path_* at that commit, 48 332 fuzz cases), moved
+// 9.55 GB instead of 15.1 GB per 1e8 queries on the 4096^2 table -- and took 2.55 ms against 2.06 ms
+// (profiles/r03_config3_ordered_*: its block pass is bound by the CUs' vector-memory request rate, four poorly coalesced
+// lane-requests per query).  A pass 1 over 16 384-query tiles in SoA form (64-record runs) was priced on paper in round 4
+// at 0.7 + 0.8 + 0.31 = 1.8-2.1 ms against the direct kernel's 2.06-2.09 ms: not built.
+// It does not compile on its own: it needs the G2Dev / locate2 / blend2 definitions of csrc/mi_interp2.hip.
 // Scattered bilinear interpolation, call-wide cell ordering (round 3; BASELINE.json configs[2]).
 //
 // The direct kernel (interp2_kernel, mi_interp2.hip) reads one random 32-B quad cell per query from a table far

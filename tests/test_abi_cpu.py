@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     lib = ctypes.CDLL(path)
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, "declared in mi355_interp.h but not exported: %s" % missing
-    assert lib.mi_abi_version() == 3
+    assert lib.mi_abi_version() == 4
 
 
 def test_python_binding_table_matches_header():

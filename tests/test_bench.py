@@ -33,7 +33,9 @@ def test_plain_multi_gpu_invocation_starts_a_launcher_child_and_relays_its_exit_
     out = _run("--gpus", "2", "--dist-backend", "gloo", "--rehearse-one-device", *SMALL)
     assert out.returncode != 0
     assert "must be launched with torch.distributed.run" not in out.stderr
-    assert out.stderr.count("bench.py needs a GPU") >= 2          # both ranks ran and said why they stopped
+    # the ranks ran and said why they stopped (the launcher may terminate the second one before it has printed, once the
+    # first has failed: one message is enough to show that the children were started and their failure relayed)
+    assert out.stderr.count("bench.py needs a GPU") >= 1
 
 
 @pytest.mark.gpu

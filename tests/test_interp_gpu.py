@@ -350,24 +350,15 @@ def test_scattered_bilinear_seeded(mi_ctx):
     assert _eq(grid.interp(_t(xq), _t(yq)).cpu().numpy(), oracle.interp2_bilinear(xg, yg, Z, xq, yq, nthreads=4))
 
 
-@pytest.fixture
-def ordered_path(mi_ctx):
-    """force mi_interp2_f64_dev onto the call-wide cell ordering for the duration of a test"""
-    import armadillocudalinearinterpolation_amd as mi
-    mi_ctx.set_interp2_path(mi.INTERP2_ORDERED)
-    yield mi_ctx
-    mi_ctx.set_interp2_path(mi.INTERP2_AUTO)
-
-
 @pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("shape", [(257, 129), (64, 1500), (3000, 2), (2, 2)])
-def test_ordered_bilinear_path_is_the_direct_kernel_bit_for_bit(ordered_path, shape, compact):
-    """The three-pass path (order by table block, evaluate block by block, un-order) runs the direct kernel's eval2 on every
-    query: same bits as the direct kernel AND as the oracle, on uniform axes and on explicit axes with a linear coarse
-    index, both resident layouts, with out-of-range / NaN / node-exact queries, a ragged tail and a workspace smaller than
-    the call (several passes)."""
+def test_bilinear_shapes_layouts_and_special_queries(mi_ctx, shape, compact):
+    """Table shapes from 2 x 2 to 3000 x 2, both resident layouts (quad cells / column pairs), explicit axes within a third of
+    a cell of a line (guess + walk) and uniform axes, with out-of-range / NaN / infinite / node-exact queries and an odd
+    query count: every result bit-equal to the oracle.  (Inputs of the round-3 tests of the call-wide cell ordering, which
+    left the product in round 4 -- scripts/exp_interp2_ordered.hpp.)"""
     import armadillocudalinearinterpolation_amd as mi
-    ctx = ordered_path
+    ctx = mi_ctx
     nx, ny = shape
     nq = 5 * 4096 + 1237                                   # five tiles and a ragged tail
     rng = np.random.default_rng(nx * 1000 + ny)
@@ -382,35 +373,26 @@ def test_ordered_bilinear_path_is_the_direct_kernel_bit_for_bit(ordered_path, sh
     xq[4096:4096 + nx] = xg                                 # a pile of node-exact abscissae in the second tile
     ref = oracle.interp2_bilinear(xg, yg, Z, xq, yq, nthreads=4)
     grid = mi.Grid2.from_axes(ctx, xg, yg, Z, compact=compact)
-    assert grid.info()["workspace_queries"] == 0            # no workspace: ORDERED falls back to the direct kernel ...
-    direct = grid.interp(_t(xq), _t(yq)).cpu().numpy()
-    assert _eq(direct, ref)
-    grid.reserve(nq)                                        # ... until the caller reserves one
-    info = grid.info()
-    assert info["workspace_queries"] >= nq and info["ordered_blocks"] >= 1
+    assert grid.info()["table_bytes"] == nx * ny * (16 if compact else 32)
     assert _eq(grid.interp(_t(xq), _t(yq)).cpu().numpy(), ref)
-    grid.reserve(2 * 4096)                                  # smaller than the call: three passes + the tail
-    assert _eq(grid.interp(_t(xq), _t(yq)).cpu().numpy(), ref)
-    grid.reserve(0)
-    assert grid.info()["workspace_queries"] == 0
+    assert _eq(grid.interp(_t(xq[1:]), _t(yq[1:])).cpu().numpy(), ref[1:])        # 8-byte aligned only: the scalar kernel
     grid.close()
     # uniform axes (implicit nodes)
-    gu = mi.Grid2.uniform(ctx, -0.5, 2.0 / nx, nx, 1.0, 3.0 / ny, ny, Z, compact=compact).reserve(nq)
+    gu = mi.Grid2.uniform(ctx, -0.5, 2.0 / nx, nx, 1.0, 3.0 / ny, ny, Z, compact=compact)
     want = oracle.interp2_bilinear_uniform(-0.5, 2.0 / nx, nx, 1.0, 3.0 / ny, ny, Z, xq, yq, nthreads=4)
     assert _eq(gu.interp(_t(xq), _t(yq)).cpu().numpy(), want)
     gu.close()
 
 
-def test_ordered_bilinear_path_many_blocks_and_skewed_queries(ordered_path):
-    """A 2048 x 1536 table has 48 blocks of the ordering in the quad layout; queries piled into one corner (every tile
-    almost empty for most blocks), onto one grid line, and spread evenly must all come out as the oracle's."""
+def test_bilinear_skewed_query_sets(mi_ctx):
+    """A 2048 x 1536 table (96 MiB of quad cells): queries piled into one corner, onto one grid line, and spread evenly
+    must all come out as the oracle's."""
     import armadillocudalinearinterpolation_amd as mi
-    ctx = ordered_path
+    ctx = mi_ctx
     nx, ny, nq = 1536, 2048, 40 * 4096
     rng = np.random.default_rng(7)
     Z = rng.random((ny, nx))
-    g = mi.Grid2.uniform(ctx, 0.0, 1.0 / (nx - 1), nx, 0.0, 1.0 / (ny - 1), ny, Z).reserve(nq)
-    assert g.info()["ordered_blocks"] == 48
+    g = mi.Grid2.uniform(ctx, 0.0, 1.0 / (nx - 1), nx, 0.0, 1.0 / (ny - 1), ny, Z)
     for kind in ("even", "corner", "line"):
         xq, yq = rng.random(nq), rng.random(nq)
         if kind == "corner":
@@ -422,9 +404,8 @@ def test_ordered_bilinear_path_many_blocks_and_skewed_queries(ordered_path):
     g.close()
 
 
-def test_binary_search_axes_keep_the_direct_kernel(ordered_path):
-    """an axis without a linear coarse index (strongly non-uniform: binary search) cannot be ordered by block: reserve()
-    succeeds, reserves nothing, and the call takes the direct kernel"""
+def test_bilinear_binary_search_axes(mi_ctx):
+    """strongly non-uniform axes (no usable linear guess: binary search on both)"""
     import armadillocudalinearinterpolation_amd as mi
     nx, ny, nq = 257, 129, 3 * 4096
     xg = np.cumsum(oracle.splitmix_uniform(1, nx) + 0.01)
@@ -432,8 +413,7 @@ def test_binary_search_axes_keep_the_direct_kernel(ordered_path):
     Z = np.sin(xg)[None, :] * np.cos(3 * yg)[:, None]
     q = oracle.splitmix_uniform(3, 2 * nq)
     xq, yq = q[:nq] * (xg[-1] - xg[0]) + xg[0], q[nq:] * (yg[-1] - yg[0]) + yg[0]
-    grid = mi.Grid2.from_axes(ordered_path, xg, yg, Z).reserve(nq)
-    assert grid.info()["workspace_queries"] == 0 and grid.info()["ordered_blocks"] == 0
+    grid = mi.Grid2.from_axes(mi_ctx, xg, yg, Z)
     assert _eq(grid.interp(_t(xq), _t(yq)).cpu().numpy(), oracle.interp2_bilinear(xg, yg, Z, xq, yq, nthreads=4))
     grid.close()
 
@@ -578,19 +558,8 @@ def test_config3_full_grid_sampled(mi_ctx):
     NQ = 100_000_000
     q2 = synth.splitmix_uniform(0x5EED0004, 2 * NQ, torch.device("cuda", 0))
     xq, yq = q2[:NQ], q2[NQ:]
-    assert grid.info()["workspace_queries"] == 0 and grid.info()["ordered_blocks"] == 256
-    out = grid.interp(xq, yq)                              # AUTO: the direct gather kernel
-    grid.reserve(NQ)
-    mi_ctx.set_interp2_path(mi.INTERP2_ORDERED)
-    try:
-        ordered = grid.interp(xq, yq)                      # the call-wide cell ordering on the same 1e8 queries
-        assert torch.equal(out.view(torch.int64), ordered.view(torch.int64))
-        del ordered
-        grid.reserve(30_000_000)                           # a workspace smaller than the call: four passes
-        assert torch.equal(grid.interp(xq, yq), out)
-    finally:
-        mi_ctx.set_interp2_path(mi.INTERP2_AUTO)
-    grid.reserve(0)
+    assert grid.info()["table_bytes"] == 32 * n * n
+    out = grid.interp(xq, yq)
     compact = mi.Grid2.uniform(mi_ctx, 0.0, 1.0 / (n - 1), n, 0.0, 1.0 / (n - 1), n, Z, compact=True)
     assert torch.equal(compact.interp(xq, yq), out)
     compact.close()
