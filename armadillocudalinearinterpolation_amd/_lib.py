@@ -95,6 +95,7 @@ SIGNATURES = {
     "mi_group_grid2_destroy": (_i32, [_vp]),
     "mi_group_interp2_f64_host": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _dbl]),
     "mi_group_interp2_f64_dev": (_i32, [_vp, _vp, _pp, _pp, _pp, _sz, _dbl, _pp]),
+    "mi_group_set_gather_chunks": (_i32, [_vp, _i32]),
     "mi_group_edm_create": (_i32, [_vp, C.POINTER(EdmParams), _pp]),
     "mi_group_edm_destroy": (_i32, [_vp]),
     "mi_group_edm_set_params": (_i32, [_vp, C.POINTER(EdmParams)]),

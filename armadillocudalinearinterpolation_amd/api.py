@@ -569,6 +569,10 @@ class Group:
     def set_reduce(self, mode):
         check(self._L.mi_group_set_reduce(self._h, int(mode)))
 
+    def set_gather_chunks(self, chunks):
+        """mi_group_set_gather_chunks: >= 2 hides the gather of interp_dev(gather=True) behind the kernels, chunk by chunk"""
+        check(self._L.mi_group_set_gather_chunks(self._h, int(chunks)))
+
     def rccl_ranks(self):
         """ranks of the group's RCCL communicator as RCCL reports it (ncclCommCount); 0: no communicator possible"""
         return int(self._L.mi_group_rccl_ranks(self._h))

@@ -43,7 +43,13 @@ struct mi_group {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     std::vector<double*> red_dev;      // MI_EDM partial blocks on the devices (RCCL reduce mode)
+    // chunked gather (mi_group_set_gather_chunks): a second stream per member for the exchange, one event per chunk
+    int gather_chunks = 1;
+    std::vector<hipStream_t> gstream;
+    std::vector<std::vector<hipEvent_t>> cdone;   // [member][chunk]: the chunk's kernel has been enqueued up to here
+    std::vector<hipEvent_t> gdone;                // [member]: its exchange stream has been enqueued up to here
 };
 
 struct mi_group_grid1 {
@@ -87,6 +93,7 @@ mi_status bind_rccl(mi_group* g)
             g->GroupStart = (decltype(g->GroupStart))dlsym(g->lib, "ncclGroupStart");
             g->GroupEnd = (decltype(g->GroupEnd))dlsym(g->lib, "ncclGroupEnd");
             g->CommCount = (decltype(g->CommCount))dlsym(g->lib, "ncclCommCount");
+            g->Broadcast = (decltype(g->Broadcast))dlsym(g->lib, "ncclBroadcast");
         }
     }
     if (!g->lib || !g->CommInitAll || !g->CommDestroy || !g->AllReduce || !g->AllGather || !g->GroupStart || !g->GroupEnd)
@@ -112,6 +119,8 @@ mi_status bind_rccl(mi_group* g)
 }  // namespace
 
 static mi_status gather_shards(mi_group* g, double* const* part_dev, double* const* gathered_dev, size_t n_per_shard);
+static mi_status interp1_chunked_gather(mi_group* g, const mi_group_grid1* t, const double* const* xq_dev, double* const* yq_dev,
+                                        size_t nq_per_shard, double extrap, double* const* gathered_dev);
 
 extern "C" {
 
@@ -167,6 +176,14 @@ mi_status mi_group_destroy(mi_group* g)
         if (r < g->red_dev.size() && g->red_dev[r]) (void)hipFree(g->red_dev[r]);
         if (r < g->comms.size() && g->comms[r] && g->CommDestroy) (void)g->CommDestroy(g->comms[r]);
         if (g->done[r]) (void)hipEventDestroy(g->done[r]);
+        if (r < g->gstream.size() && g->gstream[r]) {
+            (void)hipStreamSynchronize(g->gstream[r]);
+            (void)hipStreamDestroy(g->gstream[r]);
+        }
+        if (r < g->gdone.size() && g->gdone[r]) (void)hipEventDestroy(g->gdone[r]);
+        if (r < g->cdone.size())
+            for (hipEvent_t e : g->cdone[r])
+                if (e) (void)hipEventDestroy(e);
         mi_ctx_destroy(g->ctx[r]);
     }
     // the RCCL handle stays open for the life of the process (communicator teardown may still use it)
@@ -191,6 +208,14 @@ int mi_group_rccl_ranks(mi_group* g)
     int n = 0;
     if (g->CommCount(g->comms[0], &n) != 0) return 0;
     return n;
+}
+
+mi_status mi_group_set_gather_chunks(mi_group* g, int chunks)
+{
+    MI_REQUIRE(nullptr, g != nullptr, "mi_group_set_gather_chunks: group is NULL");
+    MI_REQUIRE(nullptr, chunks >= 1 && chunks <= 64, "mi_group_set_gather_chunks: chunks=%d not in [1,64]", chunks);
+    g->gather_chunks = chunks;
+    return MI_OK;
 }
 
 mi_status mi_group_set_reduce(mi_group* g, int mode)
@@ -256,6 +281,8 @@ mi_status mi_group_interp1_f64_dev(mi_group* g, const mi_group_grid1* t, const d
         const mi_status st = bind_rccl(g);
         if (st != MI_OK) return st;
     }
+    if (gathered_dev && g->gather_chunks > 1 && nq_per_shard >= 2 * (size_t)g->gather_chunks)
+        return interp1_chunked_gather(g, t, xq_dev, yq_dev, nq_per_shard, extrap, gathered_dev);
     for (size_t r = 0; r < P; ++r) {
         const mi_status st = mi_interp1_f64_dev(g->ctx[r], t->grid[r], xq_dev[r], yq_dev[r], nq_per_shard, extrap);
         if (st != MI_OK) return st;
@@ -366,6 +393,87 @@ static mi_status gather_shards(mi_group* g, double* const* part_dev, double* con
             MI_HIP(g->ctx[r], hipStreamWaitEvent(g->ctx[r]->stream, g->done[s], 0));
             MI_HIP(g->ctx[r], hipMemcpyAsync(dst, part_dev[s], n_per_shard * sizeof(double), hipMemcpyDeviceToDevice, g->ctx[r]->stream));
         }
+    }
+    return MI_OK;
+}
+
+// The all-gather hidden behind the kernels (north_star: "an RCCL all-gather over xGMI to reassemble the residual vector";
+// at 8 GPUs the exchange of a 1e8-query call is 0.65 ms per link against 0.1 ms of kernel): every
+// shard is cut into `gather_chunks` contiguous chunks; the kernel of chunk k+1 runs on the member's own stream while chunk k
+// travels on the member's exchange stream.  A chunk of every shard has to land at its place INSIDE that shard's slot of the
+// gathered vector (shard s at s * nq_per_shard), which ncclAllGather cannot do (it packs the pieces back to back), so a chunk
+// is exchanged as P grouped ncclBroadcast calls, root s sending its piece of the chunk (in place where yq_dev already points
+// into gathered_dev).  Repeated devices (rehearsal): the same schedule with device-to-device copies.  Results are those of the
+// unchunked call bit for bit (tests/test_group_gpu.py); the timing on a real 8-GPU node is unmeasured.
+static mi_status interp1_chunked_gather(mi_group* g, const mi_group_grid1* t, const double* const* xq_dev, double* const* yq_dev,
+                                        size_t nq_per_shard, double extrap, double* const* gathered_dev)
+{
+    const size_t P = g->ctx.size();
+    const size_t K = (size_t)g->gather_chunks;
+    if (g->distinct && !g->Broadcast) return mi::fail(nullptr, MI_ERR_HIP, "mi_group: ncclBroadcast is not exported by the loaded librccl");
+    // exchange streams and events, created on first use
+    if (g->gstream.size() != P) {
+        g->gstream.assign(P, nullptr);
+        g->gdone.assign(P, nullptr);
+        g->cdone.assign(P, std::vector<hipEvent_t>());
+    }
+    for (size_t r = 0; r < P; ++r) {
+        MI_HIP(g->ctx[r], hipSetDevice(g->dev[r]));
+        if (!g->gstream[r]) MI_HIP(g->ctx[r], hipStreamCreateWithFlags(&g->gstream[r], hipStreamNonBlocking));
+        if (!g->gdone[r]) MI_HIP(g->ctx[r], hipEventCreateWithFlags(&g->gdone[r], hipEventDisableTiming));
+        while (g->cdone[r].size() < K) {
+            hipEvent_t e = nullptr;
+            MI_HIP(g->ctx[r], hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            g->cdone[r].push_back(e);
+        }
+        // the exchange stream starts behind whatever the member's stream already holds (an earlier call may still read
+        // or write the buffers)
+        MI_HIP(g->ctx[r], hipEventRecord(g->gdone[r], g->ctx[r]->stream));
+        MI_HIP(g->ctx[r], hipStreamWaitEvent(g->gstream[r], g->gdone[r], 0));
+    }
+    size_t c = (nq_per_shard + K - 1) / K;
+    c += c & 1;                                        // even: 16-byte aligned chunk starts for the vector kernels
+    for (size_t k = 0; k * c < nq_per_shard; ++k) {
+        const size_t off = k * c, len = std::min(c, nq_per_shard - off);
+        for (size_t r = 0; r < P; ++r) {
+            const mi_status st = mi_interp1_f64_dev(g->ctx[r], t->grid[r], xq_dev[r] + off, yq_dev[r] + off, len, extrap);
+            if (st != MI_OK) return st;
+            MI_HIP(g->ctx[r], hipEventRecord(g->cdone[r][k], g->ctx[r]->stream));
+        }
+        if (g->distinct) {
+            for (size_t r = 0; r < P; ++r) {
+                MI_HIP(g->ctx[r], hipSetDevice(g->dev[r]));
+                MI_HIP(g->ctx[r], hipStreamWaitEvent(g->gstream[r], g->cdone[r][k], 0));
+            }
+            MI_NCCL(g, g->GroupStart());
+            for (size_t s = 0; s < P; ++s) {
+                for (size_t r = 0; r < P; ++r) {
+                    const ncclResult_t rc = g->Broadcast(yq_dev[r] + off, gathered_dev[r] + s * nq_per_shard + off, len, mi_ncclFloat64,
+                                                         (int)s, g->comms[r], g->gstream[r]);
+                    if (rc != 0) {
+                        (void)g->GroupEnd();
+                        return mi::fail(nullptr, MI_ERR_HIP, "ncclBroadcast failed: %s", g->GetErrorString ? g->GetErrorString(rc) : "?");
+                    }
+                }
+            }
+            MI_NCCL(g, g->GroupEnd());
+        } else {
+            for (size_t r = 0; r < P; ++r) {
+                MI_HIP(g->ctx[r], hipSetDevice(g->dev[r]));
+                for (size_t s = 0; s < P; ++s) {
+                    double* dst = gathered_dev[r] + s * nq_per_shard + off;
+                    if (dst == yq_dev[s] + off) continue;
+                    MI_HIP(g->ctx[r], hipStreamWaitEvent(g->gstream[r], g->cdone[s][k], 0));
+                    MI_HIP(g->ctx[r], hipMemcpyAsync(dst, yq_dev[s] + off, len * sizeof(double), hipMemcpyDeviceToDevice, g->gstream[r]));
+                }
+            }
+        }
+    }
+    // the member's own stream ends behind its exchange stream: mi_group_synchronize (and any later call) covers the gather
+    for (size_t r = 0; r < P; ++r) {
+        MI_HIP(g->ctx[r], hipSetDevice(g->dev[r]));
+        MI_HIP(g->ctx[r], hipEventRecord(g->gdone[r], g->gstream[r]));
+        MI_HIP(g->ctx[r], hipStreamWaitEvent(g->ctx[r]->stream, g->gdone[r], 0));
     }
     return MI_OK;
 }

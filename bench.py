@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--gather", action="store_true",
                     help="--backend group: also reassemble the whole result vector on every GPU inside the timed step "
                          "(gathered_dev of mi_group_interp1_f64_dev: an RCCL all-gather over xGMI behind the kernels)")
+    ap.add_argument("--gather-chunks", type=int, default=1,
+                    help="--backend group --gather: cut every shard into this many chunks and exchange chunk k while the kernel "
+                         "of chunk k+1 runs (mi_group_set_gather_chunks); 1 = one kernel, then one ncclAllGather")
     ap.add_argument("--config", type=int, choices=[2, 3], default=2,
                     help="2 (default): BASELINE configs[1], the 1-D headline; 3: configs[2], 4096^2 bilinear, 1e8 scattered "
                          "queries as the timed workload (for profiling interp2_kernel; same JSON contract)")
@@ -281,6 +284,8 @@ def bench_group(args):
     devices = [0] * n if args.rehearse_one_device else list(range(n))
     grp = mi.Group(devices)
     rccl_ranks = grp.rccl_ranks()                     # forms the ncclCommInitAll communicator (0: repeated devices)
+    if args.gather_chunks > 1:
+        grp.set_gather_chunks(args.gather_chunks)
     X, Y = synth.config_grid(args.ng)
     tab = grp.grid1(X, Y, sanitise=False)
     nq = args.nq - (args.nq & 1)
@@ -317,7 +322,8 @@ def bench_group(args):
         "backend": "group", "rccl_ranks": rccl_ranks,
         "config": {"workload": "1D linear interp, %.0e random queries per GPU on %.0e-point grid, fp64 (BASELINE configs[1])" % (nq, args.ng),
                    "queries_per_gpu": nq, "grid_nodes": args.ng, "table": "general",
-                   "entry_point": "mi_group_interp1_f64_dev" + (" + gathered_dev (ncclAllGather)" if args.gather else ""),
+                   "entry_point": "mi_group_interp1_f64_dev" + ((" + gathered_dev (%d chunks, grouped ncclBroadcast behind the kernels)" % args.gather_chunks
+                                                                 if args.gather_chunks > 1 else " + gathered_dev (ncclAllGather)") if args.gather else ""),
                    "sharding": "queries/%d, table replicated by mi_group_grid1_create, %s" % (
                        n, "RCCL all-gather of the result shards in the step" if args.gather else "no collective"),
                    "devices": devices},

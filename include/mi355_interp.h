@@ -363,6 +363,10 @@ mi_status mi_group_interp1_f64_host(mi_group* g, const mi_group_grid1* t, const 
 mi_status mi_group_interp1_f64_dev(mi_group* g, const mi_group_grid1* t, const double* const* xq_dev,
                                    double* const* yq_dev, size_t nq_per_shard, double extrap_val,
                                    double* const* gathered_dev);
+/* The gather of mi_group_interp1_f64_dev hidden behind its kernels: chunks >= 2 cuts every shard into that many
+ * contiguous chunks, and chunk k is exchanged (grouped ncclBroadcast on a second stream per member) while the kernel of
+ * chunk k+1 runs.  1 (default): one kernel per shard, then one ncclAllGather.  Results are identical either way. */
+mi_status mi_group_set_gather_chunks(mi_group* g, int chunks);
 
 /* 2-D table (BASELINE.json config 3) replicated on every device of the group; arguments as mi_grid2_create (host
  * pointers), the scattered queries sharded exactly as for the 1-D table. */

@@ -43,6 +43,42 @@ def test_group_interp1_host_and_device_shards(mi_ctx, devices):
     grp.close()
 
 
+@pytest.mark.parametrize("chunks", [2, 4, 7])
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_chunked_gather_equals_the_unchunked_call(mi_ctx, devices, chunks):
+    """mi_group_set_gather_chunks: the all-gather hidden behind the kernels (chunk k exchanged on a second stream -- grouped
+    ncclBroadcast on the one-rank communicator of devices [0], device-to-device copies for the repeated device -- while the
+    kernel of chunk k+1 runs) must leave every member with exactly the bytes of the unchunked call, for shard sizes that
+    do and do not divide by the chunk count, in place and out of place, call after call on the same buffers."""
+    import torch
+    import armadillocudalinearinterpolation_amd as mi
+    X, Y = _table()
+    P = len(devices)
+    grp = mi.Group(devices)
+    tab = grp.grid1(X, Y)
+    for n in (65_536 + 2, 1_000_001 if P == 1 else 300_001, 4 * chunks):
+        xi = oracle.splitmix_uniform(11 + n, P * n) * 1.1 - 0.05
+        ref = oracle.interp1_arma(X, Y, xi)
+        shards = [torch.from_numpy(xi[r * n:(r + 1) * n].copy()).cuda() for r in range(P)]
+        grp.set_gather_chunks(1)
+        outs0, full0 = tab.interp_dev(shards, gather=True)
+        grp.set_gather_chunks(chunks)
+        for rep in range(2):                               # twice: the second call reuses streams, events and buffers
+            outs, full = tab.interp_dev(shards, gather=True)
+            for r in range(P):
+                assert torch.equal(outs[r].view(torch.int64), outs0[r].view(torch.int64))
+                assert torch.equal(full[r].view(torch.int64), full0[r].view(torch.int64))
+                assert np.array_equal(full[r].cpu().numpy(), ref, equal_nan=True)
+        # in place: every member's shard already lives inside its gathered vector
+        fulls = [torch.full((P * n,), -7.0, dtype=torch.float64, device="cuda") for _ in range(P)]
+        inplace = [fulls[r][r * n:(r + 1) * n] for r in range(P)]
+        tab.interp_dev(shards, out=inplace, gather=True, gathered=fulls)
+        for r in range(P):
+            assert np.array_equal(fulls[r].cpu().numpy(), ref, equal_nan=True)
+    tab.close()
+    grp.close()
+
+
 @pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
 def test_group_interp2_host_and_device_shards(mi_ctx, devices):
     """BASELINE config 3's shape over a group: scattered bilinear queries, table replicated, query shards."""
