@@ -139,14 +139,45 @@ __device__ __forceinline__ unsigned wave_umin(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// Lexicographic (time, index) minimum over the wave ([D1]).  Times are >= 0 (|t|, 100 or +inf, never NaN), so
-// their bit patterns order like unsigned integers: two unsigned reductions give exactly the same pair as a
-// comparison tree.
-__device__ __forceinline__ void wave_argmin(float& best, unsigned& idx)
+// Wave64 unsigned maximum, same DPP pattern (identity 0).
+__device__ __forceinline__ unsigned wave_umax(unsigned v)
+{
+#define MI_DPP_MAX(ctrl, row_mask) \
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, row_mask, 0xf, false))
+    MI_DPP_MAX(0x111, 0xf);
+    MI_DPP_MAX(0x112, 0xf);
+    MI_DPP_MAX(0x114, 0xf);
+    MI_DPP_MAX(0x118, 0xf);
+    MI_DPP_MAX(0x142, 0xa);
+    MI_DPP_MAX(0x143, 0xc);
+#undef MI_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// ---- the reference's block arg-min, ties included (blockReduceMin / warpReduceMin, EventDrivenMap.cu:843-881) ----
+// On 32-wide warps the reference's shuffle trees keep the lower lane's pair only when its time is STRICTLY smaller, so a
+// tie goes to the higher lane of each step: among neurons of equal minimal time the winner is the one with the largest
+//     key(i) = rev5(i >> 5) * 32 + rev5(i & 31)              (rev5 = the 5-bit number read backwards)
+// and, in a block of fewer than 32 warps, the padding pairs (100.0f, 0) of :867-868 win whenever no time is below 100.0f
+// (result: time 100.0f, index 0).  oracle/edm_oracle.c derives this (orc_edm_argmin) and checks it against a literal
+// emulation of the trees.  `tree` = the block is made of whole warps (N a multiple of 32 -- the reference's 1024 and 512);
+// otherwise ([D1], a shape the reference cannot run) ties go to the lowest index: key(i) = 1023 - i.  Neuron indices are
+// < 1024.  A NaN time never wins ([D1]).
+__device__ __forceinline__ unsigned rev5(unsigned x) { return __brev(x) >> 27; }
+__device__ __forceinline__ unsigned tie_key(unsigned i, bool tree)
+{
+    return tree ? rev5(i >> 5) * 32u + rev5(i & 31u) : 1023u - i;
+}
+__device__ __forceinline__ unsigned tie_key_neuron(unsigned key, bool tree) { return tie_key(key, tree); }   // the map is an involution
+__device__ __forceinline__ unsigned rev4(unsigned x) { return __brev(x) >> 28; }
+
+// Minimum over the wave of (time, then LARGEST key).  Times are >= 0 (|t|, 100 or +inf, never NaN), so their bit
+// patterns order like unsigned integers: two unsigned reductions give exactly the pair a comparison tree would.
+__device__ __forceinline__ void wave_argmin(float& best, unsigned& key)
 {
     const unsigned tb = __float_as_uint(best);
     const unsigned tmin = wave_umin(tb);
-    idx = wave_umin(tb == tmin ? idx : 0xFFFFFFFFu);
+    key = wave_umax(tb == tmin ? key + 1u : 0u) - 1u;
     best = __uint_as_float(tmin);
 }
 
@@ -161,7 +192,7 @@ __device__ __forceinline__ void wave_argmin(float& best, unsigned& idx)
 // winner (only when NO neuron fires) only its index is used.  The lift kernel reports the live slices as a bit mask
 // (`store`), the host sizes the LDS for those alone -- 13 slices: 4 + 4 * 6.5 KiB = 30 KiB per workgroup, FIVE
 // workgroups (20 waves) per CU instead of four -- and the state pass never visits the others; their standing
-// contribution to the arg-min, the time kNever at the lane's lowest dead index, is kept in nan_i.
+// contribution to the arg-min, the time kNever with the largest tie key among the lane's dead neurons, is kept in nan_key.
 //
 // One workgroup per four realisations (launch_evolve): the hardware dispatcher hands them out as slots free up.
 // LDS per workgroup: w[1024] + 4 waves * (2 or 3) arrays * popcount(store)*64 floats + 4 * 64 pending-neuron slots
@@ -171,7 +202,8 @@ __device__ __forceinline__ void wave_argmin(float& best, unsigned& idx)
 // TAPS: the same computation, also counting into taps[kTap*] how often it reaches the documented decisions
 //       (mi_edm_debug_counters; never what ComputeF launches)
 enum { kTapEvents = 0, kTapMaxEvents, kTapMaxNewton, kTapNewtonCap, kTapEventCap, kTapAccepted, kTapNoFiring, kTapTies, kTapCount };
-template <int MATH, bool HETERO, int NS, bool UDIV, bool TAPS = false>
+// TREE: the block is made of whole warps (N a multiple of 32): arg-min ties as the reference breaks them (tie_key)
+template <int MATH, bool HETERO, int NS, bool UDIV, bool TAPS = false, bool TREE = true>
 __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, SpikeSeeds sd, unsigned store,
                                                               unsigned long long* __restrict__ taps,
                                                               const float* __restrict__ v0,
@@ -201,14 +233,27 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
     unsigned* list = reinterpret_cast<unsigned*>(lds + kMaxGrid + (size_t)(kEvolveBlock / 64) * kArrays * slots) + wave * 64u;   // this wave's pending neurons
     const unsigned full = (1u << M.S) - 1u;
     const float two_T = 2.0f * M.T;
-    // the same for every realisation: which of this lane's neurons exist in a live slice (bit k <-> neuron k*64+lane),
-    // and the lane's lowest neuron in a dead slice
-    unsigned valid = 0, nan_i = ~0u;
+    // arg-min ties as the reference breaks them (tie_key above); blocks that are not whole warps: lowest index
+    constexpr bool tree = TREE;
+    const bool padded = tree && (M.N >> 5) < 32u;          // the reference's second-stage padding lanes take part
+    // Slice masks (pend, valid) are kept in KEY order: slice k sits at bit pos_of(k) = rev4(k) (whole warps) or 15 - k, so
+    // that neuron k*64 + lane has the key  lane_base + (pos_of(k) << key_sh)  and the highest set bit of a mask is the
+    // slice that wins a tie -- no per-event permutation.  (Check: i >> 5 = 2k + (lane >> 5), rev5 of it is
+    // (lane >> 5) * 16 + rev4(k); and 1023 - i = (63 - lane) + 64 (15 - k).)
+    constexpr unsigned key_sh = tree ? 5u : 6u;
+    const unsigned lane_base = tree ? (lane >> 5) * 512u + rev5(lane & 31u) : 63u - lane;
+    auto pos_of = [&](unsigned k) { return tree ? rev4(k) : 15u - k; };   // an involution: also slice-of-position
+    // the same for every realisation: which of this lane's neurons exist in a live slice, and the largest tie key among
+    // the lane's neurons in dead slices (they all stand at the time kNever)
+    unsigned valid = 0, nan_key = ~0u;
     for (unsigned k = 0; k < npl; ++k) {
         const unsigned i = k * 64u + lane;
         if (i < M.N) {
-            if ((store >> k) & 1u) valid |= 1u << k;
-            else if (nan_i == ~0u) nan_i = i;
+            if ((store >> k) & 1u) valid |= 1u << pos_of(k);
+            else {
+                const unsigned key = lane_base + (pos_of(k) << key_sh);
+                if (nan_key == ~0u || key > nan_key) nan_key = key;
+            }
         }
     }
 
@@ -240,38 +285,35 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
         // fire contribute exactly kNever; the few that will (the bump fronts) need a divergent Newton solve.
         // Instead of running that loop once per 64-neuron slice, each lane records its firing neurons in a
         // bitmask (bit k <-> neuron k*64+lane) during the state pass and the solves then run in compacted
-        // rounds: one round handles one pending neuron of EVERY lane.  The (time, index) minimum is taken
-        // lexicographically, so the result does not depend on evaluation order ([D1]).
-        float base_t = INFINITY;      // min over this lane's non-firing neurons: kNever at the lowest such index
-        unsigned base_i = 0;
+        // rounds: one round handles one pending neuron of EVERY lane.  The minimum is taken lexicographically over
+        // (time, largest tie key), so the result does not depend on evaluation order.
+        unsigned base_key = ~0u;      // this lane's non-firing neurons all stand at kNever: the largest tie key among them (~0: none)
         unsigned pend = 0;
         {
             unsigned a = lane;
             for (unsigned m = store; m != 0u; m &= m - 1u, a += 64u) {
                 const unsigned k = (unsigned)__builtin_ctz(m);
                 const float bk = HETERO ? B[a] : M.beta_mean;
-                if (edm::will_fire<MATH, UDIV && !HETERO>(M, V[a], S[a], bk)) pend |= (1u << k);
+                if (edm::will_fire<MATH, UDIV && !HETERO>(M, V[a], S[a], bk)) pend |= (1u << pos_of(k));
             }
             pend &= valid;
         }
-        // the lane's lowest neuron that will not fire, from the masks (no per-slice tracking); the dead slices' standing
-        // candidate folded in
+        // the lane's neuron that will not fire and would win a tie among those (all stand at kNever): the highest bit of the
+        // quiet mask (no per-slice tracking); the dead slices' candidate folded in
         auto lowest_quiet = [&]() {
             const unsigned quiet = ~pend & valid;
-            base_t = INFINITY;
-            base_i = 0;
-            if (quiet != 0u) { base_t = edm::kNever; base_i = (unsigned)__builtin_ctz(quiet) * 64u + lane; }
-            if (nan_i != ~0u && (base_t == INFINITY || nan_i < base_i)) { base_t = edm::kNever; base_i = nan_i; }
+            base_key = quiet != 0u ? lane_base + ((31u - (unsigned)__builtin_clz(quiet)) << key_sh) : ~0u;
+            if (nan_key != ~0u && (base_key == ~0u || nan_key > base_key)) base_key = nan_key;
         };
         lowest_quiet();
         unsigned events = 0;
         unsigned tap_newton = 0, tap_cap = 0, tap_quiet = 0, tap_ties = 0;      // (TAPS only)
         while (crossed < full && now < two_T && events < M.max_events) {
             ++events;
-            float best = base_t;
-            unsigned idx = base_i;
+            float best = base_key != ~0u ? edm::kNever : INFINITY;
+            unsigned bkey = base_key;         // (~0 with best = +inf: wave_argmin reads key + 1 = 0 as "no candidate")
             // Firing-time solves, one round = the lowest pending neuron of every lane.  Which lane solves a neuron does not
-            // matter: the minimum below is lexicographic in (time, neuron index).
+            // matter: the minimum below is lexicographic in (time, tie key).
             if constexpr (MATH == 0) {
             // EXACT math: the round's neurons are compacted into `list` (rank by v_mbcnt over the ballot) and each goes to a
             // lane PAIR (j, j + 32) that shares the two software exponentials and the two IEEE divisions of a Newton
@@ -281,15 +323,16 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 const unsigned long long bal = __ballot(has);
                 const unsigned total = (unsigned)__builtin_popcountll(bal);
                 if (has) {
-                    const unsigned k = (unsigned)__builtin_ctz(pend);
+                    const unsigned pos = (unsigned)__builtin_ctz(pend);
                     pend &= pend - 1u;
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    list[rank] = k * 64u + lane;
+                    list[rank] = ((pos_of(pos) * 64u + lane) << 16) | (lane_base + (pos << key_sh));   // neuron | its tie key
                 }
                 for (unsigned base = 0; base < total; base += 32u) {      // (wave-uniform; more than once only with > 32 solves)
                     const unsigned j = base + (lane & 31u);
                     if (j < total) {
-                        const unsigned i = list[j];
+                        const unsigned entry = list[j];
+                        const unsigned i = entry >> 16, key = entry & 0xffffu;
                         const unsigned k = i >> 6;
                         const unsigned a = (unsigned)__builtin_popcount(store & ((1u << k) - 1u)) * 64u + (i & 63u);
                         const float bk = HETERO ? B[a] : M.beta_mean;
@@ -301,7 +344,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                                 tap_cap += (it >= M.max_iter) ? 1u : 0u;
                                 tap_ties += (tau == best && tau < edm::kNever) ? 1u : 0u;      // two firing neurons met in one lane
                             }
-                            if (tau < best || (tau == best && i < idx)) { best = tau; idx = i; }
+                            if (tau < best || (tau == best && key > bkey)) { best = tau; bkey = key; }
                         }
                     }
                 }
@@ -310,9 +353,9 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             // FAST math (hardware exp and reciprocal: nothing worth sharing, the pairing costs 10 %): every lane solves its own
             while (__any(pend != 0u)) {
                 if (pend != 0u) {
-                    const unsigned k = (unsigned)__builtin_ctz(pend);
+                    const unsigned pos = (unsigned)__builtin_ctz(pend);
                     pend &= pend - 1u;
-                    const unsigned i = k * 64u + lane;
+                    const unsigned k = pos_of(pos);
                     const unsigned a = (unsigned)__builtin_popcount(store & ((1u << k) - 1u)) * 64u + lane;
                     const float bk = HETERO ? B[a] : M.beta_mean;
                     uint32_t it = 0;
@@ -322,23 +365,28 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                         tap_cap += (it >= M.max_iter) ? 1u : 0u;
                         tap_ties += (tau == best && tau < edm::kNever) ? 1u : 0u;
                     }
-                    if (tau < best || (tau == best && i < idx)) { best = tau; idx = i; }
+                    const unsigned key = lane_base + (pos << key_sh);
+                    if (tau < best || (tau == best && key > bkey)) { best = tau; bkey = key; }
                 }
             }
             }
             if constexpr (TAPS) {
                 const float mine = best;
                 float bb = best;
-                unsigned ii = idx;
-                wave_argmin(bb, ii);
+                unsigned kk = bkey;
+                wave_argmin(bb, kk);
                 if (bb >= edm::kNever) tap_quiet += 1u;
                 else if (__builtin_popcountll(__ballot(mine == bb)) > 1) tap_ties += 1u;   // ... or of two lanes
             }
-            wave_argmin(best, idx);
+            wave_argmin(best, bkey);
             // the winner is the same in every lane: in scalar registers the event bookkeeping below (nearest bump,
             // crossed mask) runs on the scalar unit
-            idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
-            const float dt = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, best)));
+            unsigned idx = tie_key_neuron((unsigned)__builtin_amdgcn_readfirstlane((int)bkey), tree);
+            float dt = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, best)));
+            if (padded && !(dt < edm::kNever)) {       // no neuron fires before "never": the padding pair (100.0f, 0) wins (:867-868)
+                dt = edm::kNever;
+                idx = 0u;
+            }
             // analytic state advance (EventDrivenMap.cu:612-617), fused with the firing test for the NEXT event
             float e1, e2u = 0.0f, e3u = 0.0f;
             if constexpr (!HETERO) {
@@ -372,7 +420,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 sn = sn + (HETERO ? bk * w_lds[dist] : w_lds[dist]);
                 V[a] = vv;
                 S[a] = sn;
-                if (edm::will_fire<MATH, UDIV && !HETERO>(M, vv, sn, bk)) pend |= (1u << k);   // (padding lanes: masked below)
+                if (edm::will_fire<MATH, UDIV && !HETERO>(M, vv, sn, bk)) pend |= (1u << pos_of(k));   // (padding lanes: masked below)
             }
             pend &= valid;
             lowest_quiet();
@@ -466,6 +514,11 @@ __global__ __launch_bounds__(64 * W) void evolve_wg_kernel(edm::Model M, SpikeSe
     unsigned* red = reinterpret_cast<unsigned*>(S + slots + (HETERO ? slots : 0u));   // [2][W][2]: time bits, index
     const unsigned full = (1u << M.S) - 1u;
     const float two_T = 2.0f * M.T;
+    const bool tree = (M.N & 31u) == 0u;                   // arg-min ties as the reference breaks them (tie_key)
+    const bool padded = tree && (M.N >> 5) < 32u;
+    unsigned qkey[kMaxGrid / kBlockT];                      // tie keys of this lane's neurons, slice by slice
+#pragma unroll
+    for (unsigned k = 0; k < kMaxGrid / kBlockT; ++k) qkey[k] = tie_key((k * W + wave) * 64u + lane, tree);
     __syncthreads();
 
     for (unsigned r = blockIdx.x; r < M.R; r += gridDim.x) {
@@ -490,7 +543,7 @@ __global__ __launch_bounds__(64 * W) void evolve_wg_kernel(edm::Model M, SpikeSe
         unsigned crossed = 0;
         float now = 0.0f;
         float base_t = INFINITY;
-        unsigned base_i = 0;
+        unsigned base_key = 0;
         unsigned pend = 0;
         for (unsigned k = 0; k < npl; ++k) {
             const unsigned i = (k * W + wave) * 64u + lane;
@@ -499,19 +552,21 @@ __global__ __launch_bounds__(64 * W) void evolve_wg_kernel(edm::Model M, SpikeSe
                 if (edm::will_fire<MATH>(M, V[i], S[i], bk)) pend |= (1u << k);
             }
         }
-        // the lane's lowest neuron that will not fire, from the masks (as in evolve_kernel)
+        // the lane's neuron that will not fire and would win a tie among those (at most 1024 / (64 W) = 4 slices per lane)
         auto lowest_quiet = [&]() {
             const unsigned quiet = ~pend & valid;
-            base_t = INFINITY;
-            base_i = 0;
-            if (quiet != 0u) { base_t = edm::kNever; base_i = ((unsigned)__builtin_ctz(quiet) * W + wave) * 64u + lane; }
+            base_t = quiet != 0u ? edm::kNever : INFINITY;
+            base_key = 0;
+#pragma unroll
+            for (unsigned k = 0; k < kMaxGrid / kBlockT; ++k)
+                if (((quiet >> k) & 1u) && qkey[k] > base_key) base_key = qkey[k];
         };
         lowest_quiet();
         unsigned events = 0;
         while (crossed < full && now < two_T && events < M.max_events) {
             ++events;
             float best = base_t;
-            unsigned idx = base_i;
+            unsigned bkey = base_key;
             while (__any(pend != 0u)) {
                 if (pend != 0u) {
                     const unsigned k = (unsigned)__builtin_ctz(pend);
@@ -519,26 +574,34 @@ __global__ __launch_bounds__(64 * W) void evolve_wg_kernel(edm::Model M, SpikeSe
                     const unsigned i = (k * W + wave) * 64u + lane;
                     const float bk = HETERO ? B[i] : M.beta_mean;
                     const float tau = edm::newton_time<MATH>(M, V[i], S[i], bk);
-                    if (tau < best || (tau == best && i < idx)) { best = tau; idx = i; }
+                    unsigned key = qkey[0];
+#pragma unroll
+                    for (unsigned q = 1; q < kMaxGrid / kBlockT; ++q) key = (k == q) ? qkey[q] : key;
+                    if (tau < best || (tau == best && key > bkey)) { best = tau; bkey = key; }
                 }
             }
-            wave_argmin(best, idx);
-            // workgroup-wide lexicographic minimum through LDS (double-buffered by event parity: one barrier per event)
+            wave_argmin(best, bkey);
+            // workgroup-wide minimum of (time, largest tie key) through LDS (double-buffered by event parity: one barrier per event)
             unsigned* slot = red + (events & 1u) * (2u * W);
             if (lane == 0) {
                 slot[2u * wave] = __float_as_uint(best);
-                slot[2u * wave + 1u] = idx;
+                slot[2u * wave + 1u] = bkey;
             }
             __syncthreads();
+            unsigned idx;
             {
-                unsigned tb = slot[0], ib = slot[1];
+                unsigned tb = slot[0], kb = slot[1];
 #pragma unroll
                 for (int q = 1; q < W; ++q) {
-                    const unsigned t2 = slot[2 * q], i2 = slot[2 * q + 1];
-                    if (t2 < tb || (t2 == tb && i2 < ib)) { tb = t2; ib = i2; }
+                    const unsigned t2 = slot[2 * q], k2 = slot[2 * q + 1];
+                    if (t2 < tb || (t2 == tb && k2 > kb)) { tb = t2; kb = k2; }
                 }
                 best = __uint_as_float(tb);
-                idx = ib;
+                idx = tie_key_neuron(kb, tree);
+            }
+            if (padded && !(best < edm::kNever)) {   // the padding pair (100.0f, 0) of the reference's second stage wins (:867-868)
+                best = edm::kNever;
+                idx = 0u;
             }
             const float dt = best;
             float e1, e2u = 0.0f, e3u = 0.0f;
@@ -853,9 +916,17 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
     const int wpr = evolve_form(e);
     const bool three = e->p.n_spikes <= 3;
     if (wpr == 1) {
+    // (N not a multiple of 32 -- no launch the reference could make -- runs the !TREE instantiation: ties to the lowest index)
+    const bool whole_warps = (N & 31u) == 0u;
 #define MI_EVOLVE(H, NS, UD)                                                                                      \
-    hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, UD>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, M, sd, \
-                       live, nullptr, e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept)
+    do {                                                                                                          \
+        if (whole_warps)                                                                                          \
+            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, UD, false, true>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
+                               M, sd, live, nullptr, e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept);             \
+        else                                                                                                      \
+            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, false, false, false>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
+                               M, sd, live, nullptr, e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept);             \
+    } while (0)
         // The exact quotient by uniform divisors (edm::div_by) pays once the launch brings three or more waves per SIMD
         // (N = 512: R = 16384 10.25 -> 9.00 ms, R = 4000 3.10 -> 2.91 ms, but R = 1000 -- one wave per SIMD -- 1.59 -> 2.10 ms).
         // Round 4: with its guard down to three integer instructions it also pays at N = 1024 (137.7 -> 134.2 ms at R = 125 000).
@@ -1170,10 +1241,16 @@ mi_status mi_edm_debug_counters(mi_edm* e, uint64_t out[MI_EDM_N_COUNTERS])
         const bool hetero = e->p.beta_stddev != 0.0f, three = e->p.n_spikes <= 3;
         const size_t lds_bytes = evolve_lds_bytes(hetero, live);
         const unsigned blocks = (e->p.n_real + 3) / 4;
+        const bool whole_warps = (e->p.n_grid & 31u) == 0u;
 #define MI_TAPPED(MATH, H, NS)                                                                                              \
-    hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, false, true>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
-                       e->M, e->last_sd, live, d_taps, e->d_v, e->d_s, e->d_w, e->d_t0, e->d_i0, e->d_t1,     \
-                       e->d_i1, e->d_accept)
+    do {                                                                                                                    \
+        if (whole_warps)                                                                                                    \
+            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, false, true, true>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
+                               e->M, e->last_sd, live, d_taps, e->d_v, e->d_s, e->d_w, e->d_t0, e->d_i0, e->d_t1, e->d_i1, e->d_accept); \
+        else                                                                                                                \
+            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, false, true, false>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
+                               e->M, e->last_sd, live, d_taps, e->d_v, e->d_s, e->d_w, e->d_t0, e->d_i0, e->d_t1, e->d_i1, e->d_accept); \
+    } while (0)
         if (e->p.math_mode == MI_EDM_MATH_FAST) {
             if (hetero) { if (three) MI_TAPPED(1, true, 3); else MI_TAPPED(1, true, kMaxSpikes); }
             else { if (three) MI_TAPPED(1, false, 3); else MI_TAPPED(1, false, kMaxSpikes); }

@@ -408,10 +408,47 @@ void orc_edm_argmin_reference_tree(const float* time, uint32_t n, float* best, u
     *index = si[0];
 }
 
+/* ---- the block arg-min the event loop uses ------------------------------------
+ * The reference's reduction is deterministic on 32-wide warps, ties included, so it can be followed exactly whenever
+ * the block is made of whole warps (n a multiple of 32, as with the reference's own 1024 and 512 threads).  Reading
+ * :843-881: every step of a shuffle tree keeps the lower lane's pair only when its time is STRICTLY smaller, i.e. a tie
+ * goes to the higher lane of the step; over the steps 16, 8, 4, 2, 1 that makes the winner among tied lanes the one
+ * whose 5-bit lane number, read BACKWARDS, is largest.  The second tree does the same to the warp numbers, with the
+ * padding pairs (100.0f, 0) in the lanes >= n/32 taking part (:867-868): when no neuron fires before the "never" time
+ * 100.0f and the block has fewer than 32 warps, padding lane 31 wins and the result is (100.0f, 0).
+ *   =>  winner = the neuron of minimal time with the largest key  rev5(i >> 5) * 32 + rev5(i & 31);
+ *       if n/32 < 32 and that minimal time is not below 100.0f: (100.0f, index 0).
+ * orc_edm_argmin_reference_tree (the literal emulation above) returns the same pair on every input without NaN
+ * (tests/test_edm_oracle_cpu.py compares them on tie-laden random blocks).
+ * [D1] What is left of the decision: a NaN time never wins (taken as +inf; the reference's tree lets a NaN from the
+ * higher lane displace a number and be displaced in turn), and a block that is not made of whole warps (the reference
+ * cannot run one meaningfully: lanes of the last warp would read exited threads, :866 drops the remainder) uses
+ * "smallest time, ties to the lowest index". */
+static inline uint32_t orc_rev5(uint32_t x)
+{
+    return ((x & 1u) << 4) | ((x & 2u) << 2) | (x & 4u) | ((x & 8u) >> 2) | ((x & 16u) >> 4);
+}
+
+void orc_edm_argmin(const float* time, uint32_t n, float* best, uint32_t* index)
+{
+    float tmin = INFINITY;
+    uint32_t imin = 0;
+    const int whole_warps = (n % 32u == 0u) && n >= 32u;
+    uint32_t kmax = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float t = (time[i] != time[i]) ? INFINITY : time[i];
+        const uint32_t key = orc_rev5(i >> 5) * 32u + orc_rev5(i & 31u);
+        if (t < tmin || i == 0u) { tmin = t; imin = i; kmax = key; }
+        else if (whole_warps && t == tmin && key > kmax) { imin = i; kmax = key; }
+    }
+    if (whole_warps && n / 32u < 32u && !(tmin < 100.0f)) { tmin = 100.0f; imin = 0; }
+    *best = tmin;
+    *index = imin;
+}
+
 /* ---- EvolveKernel for one realisation (EventDrivenMap.cu:575-674) -----------
- * [D1] arg-min over neurons: smallest time, ties -> lowest index, NaN never
- *      wins (the reference's shuffle tree, :843-881, breaks ties by tree shape
- *      and treats NaN asymmetrically).
+ * [D1] arg-min over neurons: orc_edm_argmin above -- the reference's own result, ties
+ *      and padding lanes included, for blocks of whole warps; a NaN time never wins.
  * [D2] the per-bump event slots start as time 0 / index 0 (the reference
  *      leaves them uninitialised in shared memory, :580-583).
  * [D3] the bump-assignment rule `minIndex += (d_i < d_minIndex)` (:625-629) is
@@ -434,16 +471,16 @@ static void evolve_one_impl(const orc_edm_params* P, const float* v0, const floa
     float now = 0.0f;
     /* hard event cap (same rule as the HIP kernel): termination even when time cannot advance */
     while (crossed < full && now < 2.0f * T && events < P->max_events) {
-        float best = INFINITY;
-        uint32_t idx = 0;
+        float best;
+        uint32_t idx;
         uint32_t n_at_best = 0;
         uint8_t per_lane[64] = {0};
         float taus[ORC_MAX_GRID];
         for (uint32_t i = 0; i < N; ++i) {
             int it = -1;
             const float tau = event_time_impl(P, v[i], s[i], beta[i], C ? &it : NULL);
+            taus[i] = tau;
             if (C) {
-                taus[i] = tau;
                 if (tau != tau) C->nan_times += 1;
                 if (it >= 0) {
                     C->newton_solves += 1;
@@ -452,12 +489,11 @@ static void evolve_one_impl(const orc_edm_params* P, const float* v0, const floa
                     if ((uint32_t)it >= P->newton_max_iter) C->newton_cap_hits += 1;
                     per_lane[i & 63u] += 1;
                 }
-                if (tau == best) n_at_best += 1;
-                else if (tau < best) n_at_best = 1;
             }
-            if (tau < best) { best = tau; idx = i; }
         }
+        orc_edm_argmin(taus, N, &best, &idx);
         if (C) {
+            for (uint32_t i = 0; i < N; ++i) n_at_best += (taus[i] == best) ? 1u : 0u;
             if (best >= 100.0f) C->no_firing_events += 1;
             else if (n_at_best > 1) C->argmin_ties += 1;
             if (N % 32u == 0u) {

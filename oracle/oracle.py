@@ -223,6 +223,8 @@ def _edm_lib(variant=None):
         L.orc_edm_residual_from_sums.restype = None
         L.orc_edm_argmin_reference_tree.argtypes = [_f32p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.orc_edm_argmin_reference_tree.restype = None
+        L.orc_edm_argmin.argtypes = [_f32p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        L.orc_edm_argmin.restype = None
         L._edm_ready = True
     return L
 
@@ -275,6 +277,14 @@ def edm_argmin_reference_tree(times):
     times = np.ascontiguousarray(times, dtype=np.float32)
     t, i = C.c_float(0), C.c_uint32(0)
     _edm_lib().orc_edm_argmin_reference_tree(times, times.size, C.byref(t), C.byref(i))
+    return float(t.value), int(i.value)
+
+
+def edm_argmin(times):
+    """The arg-min rule the oracle's event loop uses (orc_edm_argmin: closed form of the reference's reduction): (time, index)."""
+    times = np.ascontiguousarray(times, dtype=np.float32)
+    t, i = C.c_float(0), C.c_uint32(0)
+    _edm_lib().orc_edm_argmin(times, times.size, C.byref(t), C.byref(i))
     return float(t.value), int(i.value)
 
 

@@ -143,6 +143,14 @@ def test_device_math_bit_identical_to_oracle(mi_ctx, evolve_form):
     x = np.concatenate([np.linspace(-110, 95, 300001), rng.standard_normal(200000) * 20,
                         [0.0, -0.0, np.inf, -np.inf, np.nan, 88.72284, -103.9, -87.4, 1e-30, -1e-30]]).astype(np.float32)
     assert np.array_equal(_probe(mi_ctx, 0, 0, x), oracle.edm_math_probe(0, x), equal_nan=True)      # exp, incl. subnormal results
+    # EVERY float from 88.70 to 89.5 and from -104.5 to -103.9, and the whole subnormal-result range in steps of 64 ulp: the
+    # device routine has no select for the oracle's overflow / underflow cases (ldexpf's own rounding must deliver them)
+    def every_float(lo, hi, step=1):
+        a, b = np.float32(lo).view(np.uint32), np.float32(hi).view(np.uint32)
+        return np.arange(min(a, b), max(a, b) + 1, step, dtype=np.uint32).view(np.float32)
+    xe = np.concatenate([every_float(88.70, 89.5), every_float(-103.9, -104.5), every_float(-87.0, -103.9, 64),
+                         np.array([1e30, 3.4e38, -1e30, -3.4e38, 128.0, -150.0, -151.0], np.float32)])
+    assert np.array_equal(_probe(mi_ctx, 0, 0, xe), oracle.edm_math_probe(0, xe), equal_nan=True)
     xl = np.concatenate([np.exp(rng.uniform(-100, 88, 400000)), [0.0, -1.0, np.inf, np.nan, 1e-42, 1.0]]).astype(np.float32)
     assert np.array_equal(_probe(mi_ctx, 0, 1, xl), oracle.edm_math_probe(1, xl), equal_nan=True)    # log, incl. subnormal inputs
     a = np.concatenate([rng.uniform(-5, 400, 200000), [0.0, -0.0]]).astype(np.float32)
@@ -449,3 +457,24 @@ def test_device_decision_counters_equal_the_oracles(mi_ctx, kw):
     if set(kw) <= {"n_grid", "n_real"}:
         assert dev["newton_cap_hits"] == dev["event_cap_hits"] == dev["no_firing_events"] == dev["argmin_ties"] == 0
         assert dev["accepted"] == kw["n_real"] and dev["max_newton_iter"] <= 12
+
+
+@pytest.mark.parametrize("kw", [dict(newton_max_iter=0, max_events=300), dict(I=0.5)])
+@pytest.mark.parametrize("n_grid", [1024, 512, 992, 1000, 64])
+def test_arg_min_ties_follow_the_reference_reduction(mi_ctx, n_grid, kw):
+    """Exact ties of firing times are broken as the reference's blockReduceMin breaks them on 32-wide warps
+    (EventDrivenMap.cu:843-881; oracle/edm_oracle.c orc_edm_argmin, checked there against a literal emulation of the
+    shuffle trees): newton_max_iter = 0 gives some 80 events with many-way ties of real firing times, I = 0.5 an event at
+    which nobody fires (1024 threads: neuron 1023 wins; fewer warps: the padding pair (100.0f, 0)); N = 1000 is not made of
+    whole warps (lowest index).  Every event array equal to the oracle's, in both kernel forms."""
+    kw = dict(kw, n_grid=n_grid, n_real=5)
+    edm, f, partial, dbg = _run(mi_ctx, **dict(kw))
+    c = oracle.EdmCounters()
+    fo, d = oracle.edm_compute_f(oracle.edm_default_params(**kw), Z_DRIVER, nthreads=5, counters=c)
+    for k in ("t0", "i0", "t1", "i1", "accept"):
+        assert np.array_equal(dbg[k], d[k], equal_nan=True), k
+    assert c.no_firing_events >= 5 and c.argmin_tree_mismatch == 0
+    if "newton_max_iter" in kw and n_grid >= 512:
+        assert c.argmin_ties >= 100
+    dev = edm.debug_counters()
+    assert dev["no_firing_events"] == c.no_firing_events and (dev["argmin_ties"] > 0) == (c.argmin_ties > 0)

@@ -306,3 +306,46 @@ def test_contraction_and_libm_sensitivity_is_below_newton_tolerance(n_grid):
             assert np.linalg.norm(oracle.edm_compute_f(p, uv)[0]) <= 1e-4              # the variant's root, in the oracle: 2.1e-5
             assert np.linalg.norm(oracle.edm_compute_f(p, u0, variant=variant)[0]) <= 1e-4   # and vice versa: 9.6e-5
     print("N=%d: max |delta f| over %d evaluation points, contracted and libm builds = %.3g" % (n_grid, len(points), worst))
+
+
+def test_argmin_rule_equals_the_literal_reference_reduction():
+    """D1, as far as it can be closed: on 32-wide warps the reference's blockReduceMin (EventDrivenMap.cu:843-881) is a
+    deterministic function of the block's times, ties included.  orc_edm_argmin -- the rule the oracle's event loop and both
+    HIP kernels use: minimal time, ties to the largest key rev5(i >> 5) * 32 + rev5(i & 31), and the padding pair
+    (100.0f, 0) whenever fewer than 32 warps hold no time below 100.0f -- must return exactly what the literal emulation of
+    the two shuffle trees returns, on blocks with few and many ties, all-"never" blocks, infinities, and every warp count."""
+    rng = np.random.default_rng(20240)
+    for trial in range(6000):
+        n = int(rng.choice([32, 64, 96, 256, 512, 992, 1024]))
+        kind = trial % 5
+        if kind == 0:
+            t = rng.random(n)
+        elif kind == 1:
+            t = rng.integers(0, 3, n)                                           # a few values: ties everywhere
+        elif kind == 2:
+            t = np.full(n, 100.0)                                               # nobody fires ...
+            for _ in range(int(rng.integers(0, 4))):
+                t[rng.integers(0, n)] = rng.choice([1.0, 100.0, 150.0])         # ... or almost nobody
+        elif kind == 3:
+            t = np.where(rng.random(n) < 0.9, 100.0, rng.integers(1, 4, n))
+        else:
+            t = np.where(rng.random(n) < 0.5, np.inf, rng.integers(100, 103, n))
+        t = t.astype(np.float32)
+        assert oracle.edm_argmin(t) == oracle.edm_argmin_reference_tree(t), (n, kind)
+    # the two shapes the reference runs, nobody firing: 1024 threads -> the last lane of the last warp; 512 threads -> padding
+    assert oracle.edm_argmin(np.full(1024, 100.0, np.float32)) == (100.0, 1023)
+    assert oracle.edm_argmin(np.full(512, 100.0, np.float32)) == (100.0, 0)
+    assert oracle.edm_argmin(np.array([3.0] * 8 + [2.0] + [5.0] * 23 + [2.0] * 32, np.float32)) == (2.0, 63)
+    # not whole warps (a launch the reference cannot make): ties to the lowest index, NaN never wins
+    assert oracle.edm_argmin(np.array([np.nan, 2.0, 2.0, 7.0], np.float32)) == (2.0, 1)
+
+
+@pytest.mark.parametrize("n_grid", [1024, 512, 992])
+def test_tie_laden_evolutions_agree_with_the_literal_reduction(n_grid):
+    """newton_max_iter = 0 makes every firing neuron return the time 0: some 80 events with up to ten-way exact ties of REAL
+    firing times, then one event at which nobody fires.  At every one of them the oracle's rule picks what the literal
+    reference reduction picks (argmin_tree_mismatch stays 0)."""
+    c = oracle.EdmCounters()
+    _, d = oracle.edm_compute_f(oracle.edm_default_params(n_grid=n_grid, n_real=1, newton_max_iter=0, max_events=300), Z_DRIVER, counters=c)
+    assert c.argmin_ties >= 20 and c.no_firing_events == 1 and c.argmin_tree_mismatch == 0
+    assert int(d["i1"].max()) == (1023 if n_grid == 1024 else 0)       # who "fires" when nobody does: :867-868's padding or lane 1023
