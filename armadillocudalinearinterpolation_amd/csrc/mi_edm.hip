@@ -227,9 +227,12 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
     __syncthreads();
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     constexpr unsigned kArrays = HETERO ? 3u : 2u;
+    // per wave: the live slices' (v, s) side by side -- slice j holds v at [128 j, 128 j + 64) and s 64 floats further, so that one
+    // ds_read2st64_b32 / ds_write2st64_b32 moves both -- then, for per-neuron beta only, the slices' beta values
     float* V = lds + kMaxGrid + (size_t)wave * kArrays * slots;
-    float* S = V + slots;
-    float* B = S + slots;   // only touched when HETERO
+    float* S = V + 64;
+    float* B = V + 2u * slots;   // only touched when HETERO; neuron at V[a] has its beta at B[bidx(a)]
+    auto bidx = [&](unsigned a) { return ((a - lane) >> 1) + lane; };
     unsigned* list = reinterpret_cast<unsigned*>(lds + kMaxGrid + (size_t)(kEvolveBlock / 64) * kArrays * slots) + wave * 64u;   // this wave's pending neurons
     const unsigned full = (1u << M.S) - 1u;
     const float two_T = 2.0f * M.T;
@@ -261,12 +264,12 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
     for (unsigned r = blockIdx.x * (kEvolveBlock / 64) + wave; r < M.R; r += waves_per_grid) {
         {
             unsigned a = lane;
-            for (unsigned m = store; m != 0u; m &= m - 1u, a += 64u) {
+            for (unsigned m = store; m != 0u; m &= m - 1u, a += 128u) {
                 const unsigned i = (unsigned)__builtin_ctz(m) * 64u + lane;
                 const bool act = i < M.N;
                 V[a] = act ? v0[i] : 0.0f;
                 S[a] = act ? s0[i] : 0.0f;
-                if constexpr (HETERO) B[a] = edm::beta_of<MATH>(M.beta_mean, M.beta_sigma, M.seed, M.N, (uint64_t)r + M.real_offset, act ? i : 0u);
+                if constexpr (HETERO) B[bidx(a)] = edm::beta_of<MATH>(M.beta_mean, M.beta_sigma, M.seed, M.N, (uint64_t)r + M.real_offset, act ? i : 0u);
             }
         }
         // per-bump event slots ([D2]: start at time 0 / index 0); wave-uniform values
@@ -291,9 +294,9 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
         unsigned pend = 0;
         {
             unsigned a = lane;
-            for (unsigned m = store; m != 0u; m &= m - 1u, a += 64u) {
+            for (unsigned m = store; m != 0u; m &= m - 1u, a += 128u) {
                 const unsigned k = (unsigned)__builtin_ctz(m);
-                const float bk = HETERO ? B[a] : M.beta_mean;
+                const float bk = HETERO ? B[bidx(a)] : M.beta_mean;
                 if (edm::will_fire<MATH, UDIV && !HETERO>(M, V[a], S[a], bk)) pend |= (1u << pos_of(k));
             }
             pend &= valid;
@@ -334,8 +337,9 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                         const unsigned entry = list[j];
                         const unsigned i = entry >> 16, key = entry & 0xffffu;
                         const unsigned k = i >> 6;
-                        const unsigned a = (unsigned)__builtin_popcount(store & ((1u << k) - 1u)) * 64u + (i & 63u);
-                        const float bk = HETERO ? B[a] : M.beta_mean;
+                        const unsigned sl = (unsigned)__builtin_popcount(store & ((1u << k) - 1u));
+                        const unsigned a = sl * 128u + (i & 63u);
+                        const float bk = HETERO ? B[sl * 64u + (i & 63u)] : M.beta_mean;
                         uint32_t it = 0;
                         const float tau = edm::newton_time_paired<MATH, UDIV && !HETERO>(M, V[a], S[a], bk, lane >= 32u, TAPS ? &it : nullptr);
                         if (lane < 32u) {
@@ -356,8 +360,8 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                     const unsigned pos = (unsigned)__builtin_ctz(pend);
                     pend &= pend - 1u;
                     const unsigned k = pos_of(pos);
-                    const unsigned a = (unsigned)__builtin_popcount(store & ((1u << k) - 1u)) * 64u + lane;
-                    const float bk = HETERO ? B[a] : M.beta_mean;
+                    const unsigned a = (unsigned)__builtin_popcount(store & ((1u << k) - 1u)) * 128u + lane;
+                    const float bk = HETERO ? B[bidx(a)] : M.beta_mean;
                     uint32_t it = 0;
                     const float tau = edm::newton_time<MATH, UDIV && !HETERO>(M, V[a], S[a], bk, TAPS ? &it : nullptr);
                     if constexpr (TAPS) {
@@ -403,24 +407,29 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             constexpr int kStateUnroll = HETERO ? 4 : 1;      // measured (DESIGN_HISTORY.md): rolled, per-neuron beta 4x
             unsigned a = lane;
 #pragma unroll kStateUnroll
-            for (unsigned m = store; m != 0u; m &= m - 1u, a += 64u) {      // live slices only
+            for (unsigned m = store; m != 0u; m &= m - 1u, a += 128u) {      // live slices only
                 const unsigned k = (unsigned)__builtin_ctz(m);
                 const unsigned i = k * 64u + lane;
-                const float bk = HETERO ? B[a] : M.beta_mean;
+                const float bk = HETERO ? B[bidx(a)] : M.beta_mean;
                 const float e2 = HETERO ? edm::expf_<MATH>((1.0f - bk) * dt) : e2u;
                 const float e3 = HETERO ? edm::expf_<MATH>(-bk * dt) : e3u;
                 const float so = S[a];
                 float vv = V[a] * e1;
                 vv = vv + (M.I * (1.0f - e1) + edm::div_by<MATH, UDIV && !HETERO>(so * e1, 1.0f - bk) * (e2 - 1.0f));
                 // reset of the neuron that fired (:615 multiplies every v by (tid != index)): x * 1 == x, so only that
-                // neuron needs the multiply (by 0: NaN stays NaN, a finite value becomes a signed zero)
-                vv = (i == idx) ? vv * 0.0f : vv;
+                // neuron needs the multiply (by 0: NaN stays NaN, a finite value becomes a signed zero) -- and only its
+                // slice looks for it (a scalar branch: idx and k are wave-uniform)
+                if (k == (idx >> 6)) {
+                    asm volatile("" : "+v"(vv));      // (keeps the compiler from turning the branch into a select on every slice)
+                    vv = (lane == (idx & 63u)) ? vv * 0.0f : vv;
+                }
                 float sn = so * e3;
-                const unsigned dist = (unsigned)abs((int)i - (int)idx);   // < kMaxGrid: i < npl*64 <= kMaxGrid, idx < N
+                unsigned dist;                                            // |i - idx| < kMaxGrid: i < npl*64 <= kMaxGrid, idx < N
+                asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dist) : "v"(i), "s"(idx));
                 sn = sn + (HETERO ? bk * w_lds[dist] : w_lds[dist]);
                 V[a] = vv;
                 S[a] = sn;
-                if (edm::will_fire<MATH, UDIV && !HETERO>(M, vv, sn, bk)) pend |= (1u << pos_of(k));   // (padding lanes: masked below)
+                pend |= (edm::will_fire<MATH, UDIV && !HETERO>(M, vv, sn, bk) ? 1u : 0u) << pos_of(k);   // (padding lanes: masked below)
             }
             pend &= valid;
             lowest_quiet();
