@@ -206,7 +206,7 @@ mi_status mi_interp1_f64_host(mi_ctx* ctx, const mi_grid1* g, const double* xq, 
     st = mi::ensure_scratch(ctx, 1, bytes);
     if (st != MI_OK) return st;
     // Chunks of 8 M queries: the copy back of chunk k (aux stream) overlaps the upload of chunk k+1 (main stream) --
-    // PCIe carries both directions at once (scripts/exp_pcie.hip: 0.8 GB each way 14 + 14 ms one after the other,
+    // PCIe carries both directions at once (harness exp_pcie.hip, scripts/ARCHIVE.md: 0.8 GB each way 14 + 14 ms one after the other,
     // 16.5 ms together); the kernel is 4 % of either copy.  Small calls keep the single-shot form.
     const size_t chunk = (size_t)8 << 20;
     if (nq <= 2 * chunk) {

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kSweepThreads) void interp1_sweep_kernel(G1Dev g, c
 
 // ---- region sweep, pipelined form (round 2) ----------------------------------------------------------------
 // Same tiles, same in-LDS counting sort, same arithmetic as interp1_sweep_kernel, but the HBM streams of one tile run
-// WHILE another tile gathers.  Measured (scripts/exp_mix.hip, profiles/r02_exp_mix.log): stream loads or stores issued
+// WHILE another tile gathers.  Measured (profiles/r02_exp_mix_stream_beside_gathers.log; harness: scripts/ARCHIVE.md): stream loads or stores issued
 // by OTHER waves of the CU, a few wave-instructions at a time, cost the L2-hit gathers of the gathering waves about
 // 12 % -- what hurt every overlap scheme of round 1 was the burst (all CUs loading 128 KiB at the same moment) and
 // loads issued by the gathering waves themselves (vmcnt is in order within a wave).  So: one 1024-lane workgroup per
