@@ -19,6 +19,17 @@ Multi-GPU: the query axis shards trivially: every rank owns its o
 replica of the table; there is no data-path collective in the timed region ("scaling": "weak").  The optional
 all-gather that reassembles the full result vector on every rank is timed separately (extra.allgather_ms).
 
+What to expect from the headline, up front (profiles/r04_bench_rocprof_summary.json,
+profiles/r03_exp_gather_rate_vs_active_cus.log): uniformly random queries over a table larger than an XCD's L2 are bound by
+ONE L2 REQUEST PER QUERY -- an XCD's vector request path takes about 33 per ns, so the launch's 115.0 M requests need at
+least 0.44 ms: 46 % of 8 TB/s is the ceiling of any single-pass design on this metric, and the shipped kernel measures
+0.68 ms = 29.4 % (roofline.request_floor_ms_at_measured_cap carries the floor in every line).  north_star's >= 70 % holds for
+ordered query sets: extra.general_sorted (77.5 %), extra.general_uniformq (the set XI_j = j/(NQ-1): 69.7 %).
+
+Every line -- any N, --backend group, --config 3 -- carries cpu_baseline (the CPU oracle on this box's host cores: the whole
+1e8-query set at N = 1, a 2e7-query sample by rank 0 at N > 1), and at N > 1 extra.n1_reference_ms: rank 0 repeating the
+same step alone, so that the 1 -> N ratio can be formed from one line.
+
 Rank 0 prints ONE JSON line (the last line of stdout).
 """
 import argparse
