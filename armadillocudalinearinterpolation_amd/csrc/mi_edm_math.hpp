@@ -290,18 +290,31 @@ MI_HD float newton_time(const Model& M, float v0, float s0, float beta, uint32_t
     return fabsf(t);
 }
 
-// the value x holds in lane (lane ^ 32) of the wave; both lanes of the pair must be active.  upper = lane >= 32.
-// (v_permlane32_swap_b32: one VALU instruction, no LDS round trip)
-__device__ __forceinline__ float other_half(float x, bool upper)
+// v_permlane32_swap_b32 on (x, x): one VALU instruction, no LDS round trip.  It exchanges the upper half of its first
+// operand with the lower half of its second, so with both operands = x the first comes back holding the LOWER lane's
+// value in both lanes of every pair (l, l + 32) and the second the UPPER lane's value in both.  Both lanes of a pair
+// must be active.
+__device__ __forceinline__ void pair_values(float x, float& of_lower, float& of_upper)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, upper ? r[0] : r[1]);
+    // Written as inline assembly: with ROCm 7.2's clang the builtin's SECOND result is folded into its first at -O3 whenever
+    // the two are used separately (`r[1]` becomes `extractvalue 0`; the -O0 lowering is right), which would silently hand
+    // both lanes the lower lane's value.  s_nop 1: the wait states a VALU write of either operand needs before the swap
+    // reads it (what the compiler inserts in front of its own v_permlane32_swap).
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    of_lower = a;
+    of_upper = b;
 #else
-    (void)upper;
-    return x;      // (the host pass only parses the kernels)
+    of_lower = of_upper = x;      // (the host pass only parses the kernels)
 #endif
+}
+// the value x holds in lane (lane ^ 32) of the wave (test probe).  upper = lane >= 32.
+__device__ __forceinline__ float other_half(float x, bool upper)
+{
+    float lo, hi;
+    pair_values(x, lo, hi);
+    return upper ? lo : hi;
 }
 
 // newton_time() for a neuron given to the lane PAIR (l, l + 32), both holding the same (v0, s0, beta): the lower lane
@@ -324,8 +337,8 @@ __device__ __forceinline__ float newton_time_paired(const Model& M, float v0, fl
     while ((fabsf(f) > M.tol_f) && (counter < M.max_iter)) {
         t = t - div_<MATH>(f, df);
         const float e = expf_<MATH>(cx * t);              // lower: exp(-t); upper: exp((1 - beta) t)
-        const float eo = other_half(e, upper);
-        const float e1 = upper ? eo : e, e2 = upper ? e : eo;
+        float e1, e2;
+        pair_values(e, e1, e2);                           // both lanes now hold both exponentials
         const float se = s0 * e1;
         const float em1 = e2 - 1.0f;
         float q = div_by<MATH, UNI>(upper ? se * em1 : se, omb);
@@ -333,10 +346,7 @@ __device__ __forceinline__ float newton_time_paired(const Model& M, float v0, fl
         const float ve = v0 * e1;
         const float fv = ((ve + M.I * (1.0f - e1)) + q * em1) - M.vth;     // :546 (meaningful in the lower lane)
         const float dv = ((M.I * e1 - ve) + se * e2) + q;                  // :551 (meaningful in the upper lane)
-        const float mine = upper ? dv : fv;
-        const float theirs = other_half(mine, upper);
-        f = upper ? theirs : mine;
-        df = upper ? mine : theirs;
+        pair_values(upper ? dv : fv, f, df);              // the lower lane's f and the upper lane's f' to both
         ++counter;
     }
     if (iters) *iters = counter;
