@@ -404,9 +404,8 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             } else {
                 e1 = edm::expf_<MATH>(-dt);
             }
-            constexpr int kStateUnroll = HETERO ? 4 : 1;      // measured (DESIGN_HISTORY.md): rolled, per-neuron beta 4x
             unsigned a = lane;
-#pragma unroll kStateUnroll
+#pragma unroll 1                                                            // rolled: measured (DESIGN_HISTORY.md section 4)
             for (unsigned m = store; m != 0u; m &= m - 1u, a += 128u) {      // live slices only
                 const unsigned k = (unsigned)__builtin_ctz(m);
                 const unsigned i = k * 64u + lane;
