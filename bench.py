@@ -491,7 +491,13 @@ def main():
         reps = max(3, min(args.steps, 10))
 
         def quick(fn):
-            _, e = timed_loop(ctx, fn, reps, 2, lambda: None)
+            # every secondary measurement starts from the same device state: a sustained run of 6 TB/s streaming launches
+            # drifts up by 5-8 % within a dozen calls (profiles/r04_order_probe_trace.log: whichever ordered set is timed
+            # second looks slower), so the device idles for 50 ms first; 3 untimed calls cover the one call that the
+            # query-order probe mispredicts after a change of query set
+            torch.cuda.synchronize()
+            time.sleep(0.05)
+            _, e = timed_loop(ctx, fn, reps, 3, lambda: None)
             return e / reps
 
         xs = torch.sort(xq).values

@@ -16,7 +16,11 @@ def run(budget, seed, ctx=None):
     rng = np.random.default_rng(seed)
     ctx = ctx or mi.Context(0)
     t0, cases, accepted = time.time(), 0, 0
+    beat = t0
     while time.time() - t0 < budget:
+        if time.time() - beat > 60.0:          # a sign of life every minute (a silent GPU command is taken to be hung)
+            beat = time.time()
+            print("  ... %d cases after %.0f s" % (cases, beat - t0), flush=True)
         S = int(rng.choice([1, 2, 3, 3, 3, 4, 5]))
         kw = dict(
             n_grid=int(rng.choice([64, 100, 256, 500, 512, 1000, 1024])), n_real=int(rng.choice([1, 2, 3, 5, 9])),

@@ -38,7 +38,11 @@ def run(budget, seed, ctx=None):
     t0, cases, modes = time.time(), 0, {}
     kinds = ["linspace", "arange", "jitter", "wide_jitter", "power", "cumsum", "stretched"]
     sizes = [2, 3, 7, 64, 1000, 4095, 8191, 8192, 16383, 16384, 40000, 700000, 1200000]
+    beat = t0
     while time.time() - t0 < budget:
+        if time.time() - beat > 60.0:          # a sign of life every minute (a silent GPU command is taken to be hung)
+            beat = time.time()
+            print("  ... %d cases after %.0f s" % (cases, beat - t0), flush=True)
         kind = kinds[rng.integers(len(kinds))]
         n = int(sizes[rng.integers(len(sizes))])
         X = np.ascontiguousarray(grid_family(rng, kind, n))

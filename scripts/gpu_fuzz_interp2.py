@@ -27,7 +27,11 @@ def run(budget, seed, ctx=None):
     rng = np.random.default_rng(seed)
     ctx = ctx or mi.Context(0)
     t0, cases, scalar = time.time(), 0, 0
+    beat = t0
     while time.time() - t0 < budget:
+        if time.time() - beat > 60.0:          # a sign of life every minute (a silent GPU command is taken to be hung)
+            beat = time.time()
+            print("  ... %d cases after %.0f s" % (cases, beat - t0), flush=True)
         nx, ny = (int(rng.choice([2, 3, 17, 64, 255, 700])) for _ in range(2))
         uniform = rng.random() < 0.35
         if uniform:
