@@ -191,6 +191,18 @@ def measured_traffic(mode, queries, nq):
     return None, "no committed PMC profile covers this configuration", {}
 
 
+def measured_traffic_config3(nq):
+    """fabric bytes per interp2_kernel launch from the committed PMC profile, quoted only for the same interp2 sources"""
+    try:
+        from armadillocudalinearinterpolation_amd import _build
+        e = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json"))).get("interp2_random")
+        if e and int(e.get("nq", 0)) == int(nq) and e.get("source_sha256") == _build.source_hash("interp2"):
+            return e["hbm_bytes_per_launch"], "rocprofv3 PMC passes of this build (scripts/profile_bench.sh ... --config 3), profiles/traffic_latest.json"
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, "no committed PMC profile covers this configuration / build"
+
+
 def kernel_label(args, ginfo, nq, info):
     """which kernel launch_mode (csrc/mi_interp1.hip) picks for this call: region sweep for unordered queries over a table
     beyond L2 with at least SWEEP_MIN_TILES_PER_CU tiles per CU (pipelined form from 16 tiles per CU), else streaming"""
@@ -242,7 +254,8 @@ def bench_config3(args, ctx, info, dev, world, rank, barrier, dist, dist_on):
                        "entry_point": "mi_interp2_f64_dev",
                        "path": "interp2_kernel, one random cell per query"},
             "roofline": {"bound": "hbm", "achieved": alg / ks / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": alg / ks / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": alg / ks / 1e9 / HBM_PEAK_GBPS, "traffic": measured_traffic_config3(nq)[0],
+                         "traffic_note": measured_traffic_config3(nq)[1],
                          "kernel": "interp2_kernel",
                          "kernel_ms": ks * 1e3, "algorithmic_bytes_per_launch": alg},
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_config3(n3, nq),

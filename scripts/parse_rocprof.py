@@ -108,6 +108,12 @@ def main():
                           "tallies every fabric read at 64 B): reads = 128*TCC_EA0_RDREQ_128B + 64*_64B + 32*_32B, writes = "
                           "WRITE_SIZE*1024; without the size classes the 'doubled' figure (2*FETCH_SIZE + WRITE_SIZE)*1024; "
                           "Infinity-Cache hits are counted"}
+        m2 = re.search(r"interp2_kernel<", k)
+        if m2:
+            latest["interp2_%s" % queries] = {
+                "nq": nq, "hbm_bytes_per_launch": t["hbm_bytes_per_launch_by_request_size"] or t["hbm_bytes_per_launch_doubled"],
+                "kernel": k, "profile": "summary_%s.json" % tag, "family": "interp2",
+                "method": "reads = 128*TCC_EA0_RDREQ_128B + 64*_64B + 32*_32B, writes = WRITE_SIZE*1024 (separate rocprofv3 --pmc passes)"}
     # the L2 request roofline of the dominant kernel: requests served per launch / (128 channels x one request per clock)
     if dom and dom in pm and "TCC_REQ_sum" in pm[dom]:
         req = pm[dom]["TCC_REQ_sum"]["per_dispatch_median"]
@@ -144,7 +150,7 @@ def main():
         except Exception:
             stamp = None
         for e in latest.values():
-            e["source_sha256"] = stamp
+            e["source_sha256"] = _build.source_hash(e.get("family", "interp1")) if stamp else None
         json.dump(latest, open(os.path.join(out_dir, "traffic_latest.json"), "w"), indent=1)
     dst = os.path.join(out_dir, "summary_%s.json" % tag)
     json.dump(summary, open(dst, "w"), indent=1)

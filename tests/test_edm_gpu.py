@@ -423,6 +423,12 @@ def test_config4_per_gpu_share_125k_realisations(mi_ctx):
     assert np.all(dbg["accept"] == 1) and partial[3] == R
     assert np.array_equal(dbg["restricted"].reshape(3, R)[:, 0], d["restricted"])
     assert np.array_equal(partial[:3], (R - 1) * x) and np.array_equal(f, fref(R, True))
+    # the decision-coverage taps over the whole share: 848 events in every realisation, at most 9 Newton iterations, no cap
+    # reached, no event without a firing neuron, no exact tie -- none of D0 / D1 / D8 is exercised on config 4's inputs
+    taps = edm.debug_counters()
+    assert taps["accepted"] == R and taps["events"] == R * taps["max_events_one"] and taps["max_events_one"] == 848
+    assert taps["max_newton_iter"] <= 9 and taps["newton_cap_hits"] == 0 and taps["event_cap_hits"] == 0
+    assert taps["no_firing_events"] == 0 and taps["argmin_ties"] == 0
     edm.params.mean_quirk = 0
     edm._push()
     ft, pt = edm.ComputeF(Z_DRIVER, want_partial=True)
