@@ -504,13 +504,14 @@ def main():
         reps = max(3, min(args.steps, 10))
 
         def quick(fn):
-            # every secondary measurement starts from the same device state: a sustained run of 6 TB/s streaming launches
-            # drifts up by 5-8 % within a dozen calls (profiles/r04_order_probe_trace.log: whichever ordered set is timed
-            # second looks slower), so the device idles for 50 ms first; 3 untimed calls cover the one call that the
-            # query-order probe mispredicts after a change of query set
-            torch.cuda.synchronize()
-            time.sleep(0.05)
-            _, e = timed_loop(ctx, fn, reps, 3, lambda: None)
+            # Steady state for the secondary measurements: after any idle of the device (table construction, host work) the
+            # first ~8 launches run fast, the next ~50 up to 35 % slower, and only after ~20 ms of continuous launches does
+            # the time per call settle (profiles/r04_order_probe_trace.log: 0.25 -> 0.34 -> 0.255 ms for the ordered sets);
+            # one call after a change of query set also runs the kernel predicted for the previous set.  So: 30 ms of
+            # untimed calls first, then `reps` timed ones.  (The headline above keeps the contract's W warm-up steps.)
+            _, e0 = timed_loop(ctx, fn, 3, 2, lambda: None)
+            warm = min(400, max(3, int(0.03 / max(e0 / 3, 1e-5))))
+            _, e = timed_loop(ctx, fn, reps, warm, lambda: None)
             return e / reps
 
         xs = torch.sort(xq).values

@@ -1,7 +1,7 @@
-"""Per-call times of mi_interp1_f64_dev with the query order left to the device-side probe (AUTO), across changes of the
-query set: how many calls after a change still run the kernel predicted for the previous set?  (not a test)"""
+"""Per-call ms of ordered query sets after a run of random ones, with different idle times in between (not a test)."""
 import os
 import sys
+import time
 
 import torch
 
@@ -19,12 +19,32 @@ xs = torch.sort(xr).values
 xu = torch.arange(NQ, dtype=torch.float64, device=dev) / (NQ - 1)
 out = torch.empty_like(xr)
 tm = ctx.timer()
-for name, q in (("random", xr), ("sorted", xs), ("uniform", xu), ("random", xr), ("uniform", xu), ("sorted", xs)):
+
+
+def run(q, n):
     ts = []
-    for _ in range(8):
+    for _ in range(n):
         tm.start()
         grid.interp(q, out=out)
         tm.stop()
         torch.cuda.synchronize()
         ts.append(tm.elapsed_ms())
-    print("%-8s" % name, " ".join("%.3f" % t for t in ts), flush=True)
+    return ts
+
+
+for idle in (0.0, 0.05, 1.0, 3.0):
+    run(xr, 25)
+    for name, q in (("sorted", xs), ("uniform", xu), ("sorted", xs), ("uniform", xu)):
+        torch.cuda.synchronize()
+        time.sleep(idle)
+        ts = run(q, 14)
+        print("idle %.2f s %-8s" % (idle, name), " ".join("%.3f" % t for t in ts), flush=True)
+
+# how long does the dip after an idle last?
+torch.cuda.synchronize()
+time.sleep(0.05)
+ts = run(xs, 120)
+print("after 50 ms idle, 120 sorted calls:", " ".join("%.3f" % t for t in ts), flush=True)
+run(xr, 25)
+ts = run(xs, 120)
+print("right after 25 random calls, 120 sorted calls:", " ".join("%.3f" % t for t in ts), flush=True)
