@@ -24,7 +24,7 @@ profiles/r03_exp_gather_rate_vs_active_cus.log): uniformly random queries over a
 ONE L2 REQUEST PER QUERY -- an XCD's vector request path takes about 33 per ns, so the launch's 115.0 M requests need at
 least 0.44 ms: 46 % of 8 TB/s is the ceiling of any single-pass design on this metric, and the shipped kernel measures
 0.68 ms = 29.4 % (roofline.request_floor_ms_at_measured_cap carries the floor in every line).  north_star's >= 70 % holds for
-ordered query sets: extra.general_sorted (77.5 %), extra.general_uniformq (the set XI_j = j/(NQ-1): 69.7 %).
+ordered query sets: extra.general_sorted (78.2 %), extra.general_uniformq (the set XI_j = j/(NQ-1): 77.7 %).
 
 Every line -- any N, --backend group, --config 3 -- carries cpu_baseline (the CPU oracle on this box's host cores: the whole
 1e8-query set at N = 1, a 2e7-query sample by rank 0 at N > 1), and at N > 1 extra.n1_reference_ms: rank 0 repeating the
