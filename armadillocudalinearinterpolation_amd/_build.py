@@ -30,12 +30,12 @@ def source_hash(family=None):
     """sha256 over the device / ABI sources the library is built from (sorted paths, contents only): what a committed
     profile is stamped with, so that bench.py can tell whether a measured traffic figure belongs to the running build.
     family="interp1" / "interp2" / "edm": only the sources that kernel family is compiled from (mi_<family>*, mi_common.hpp,
-    mi_ctx.hip and the ABI header), so that work on another kernel family does not orphan a traffic profile."""
+    mi_ctx.hip), so that work on another kernel family -- or a comment in the ABI header -- does not orphan a traffic profile."""
     import hashlib
     h = hashlib.sha256()
     for p in sorted(_deps()):
         b = os.path.basename(p)
-        if family and not (b.startswith("mi_" + family) or b in ("mi_common.hpp", "mi_ctx.hip", "mi355_interp.h")):
+        if family and not (b.startswith("mi_" + family) or b in ("mi_common.hpp", "mi_ctx.hip")):
             continue
         h.update(b.encode())
         h.update(open(p, "rb").read())

@@ -273,7 +273,9 @@ mi_status mi_edm_set_kernel_choice(mi_edm* e, int waves_per_realisation, int uni
  * applies mean_quirk); when partial is non-NULL f is still the single-device
  * residual. */
 mi_status mi_edm_compute_f(mi_edm* e, const double* z, double* f, double* partial);
-/* The same in two halves: _begin enqueues the whole evaluation on the context's stream and returns at once,
+/* The same in two halves: _begin enqueues the whole evaluation on the context's stream and returns (with 600 or more
+ * realisations it first waits for the lift kernel -- microseconds -- because the evolve kernel's LDS is sized by the
+ * lift profile's live slices; the evolve kernel itself, which is > 99.9 % of the evaluation, is never waited for),
  * _end waits for it and forms f (and partial).  Independent evaluations -- the columns of NewtonSolver's
  * finite-difference Jacobian (NewtonSolver.cpp:178-197) -- can then overlap on the device: one mi_ctx (with its own
  * stream) and one mi_edm per evaluation in flight, _begin on all of them, _end on all of them.  One evaluation per
