@@ -716,7 +716,10 @@ __global__ void math_probe_kernel(int op, const float* a, const float* b, float*
         case 0: r = edm::expf_<MATH>(a[i]); break;
         case 1: r = edm::logf_<MATH>(a[i]); break;
         case 2: r = edm::powf_<MATH>(a[i], b[i]); break;
-        case 4: r = edm::div_by<MATH, true>(a[i], b[0]); break;    // quotient by a wave-uniform divisor (b[0])
+        case 4:                                                   // quotient by a launch-uniform divisor (b[0]) as a launch takes it:
+            r = (fabsf(b[0]) >= 0x1.0p-20f && fabsf(b[0]) <= 0x1.0p+20f)   // the five-operation form only for divisors the host gate
+                    ? edm::div_by<MATH, true>(a[i], b[0]) : a[i] / b[0];  // admits (launch_evolve: uniform_divisors_ok), else IEEE
+            break;
         case 5: r = a[i] / b[0]; break;                           // the IEEE expansion, for comparison
         case 6: case 7: case 8: case 9: case 10: case 11: {       // will_fire(v0 = a, s0 = b): exact path (even op) / with the
             edm::Model M = {};                                    // hardware pre-decision (odd op); beta by op pair
@@ -938,7 +941,10 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
         // The exact quotient by uniform divisors (edm::div_by) pays once the launch brings three or more waves per SIMD
         // (N = 512: R = 16384 10.25 -> 9.00 ms, R = 4000 3.10 -> 2.91 ms, but R = 1000 -- one wave per SIMD -- 1.59 -> 2.10 ms).
         // Round 4: with its guard down to three integer instructions it also pays at N = 1024 (137.7 -> 134.2 ms at R = 125 000).
-        const bool udiv = MATH == 0 && !hetero && Reff >= cus * 12u && !e->no_uniform_div;
+        // (edm::div_by<.., true> relies on its divisors -- 1 - beta, beta - 1 and vth - I -- lying in [2^-20, 2^20] in magnitude)
+        auto in_range = [](float c) { return fabsf(c) >= 0x1.0p-20f && fabsf(c) <= 0x1.0p+20f; };
+        const bool uniform_divisors_ok = in_range(1.0f - e->p.beta_mean) && in_range(e->p.beta_mean - 1.0f) && in_range(e->p.vth - e->p.I);
+        const bool udiv = MATH == 0 && !hetero && Reff >= cus * 12u && !e->no_uniform_div && uniform_divisors_ok;
         if (hetero) { if (three) MI_EVOLVE(true, 3, false); else MI_EVOLVE(true, kMaxSpikes, false); }
         else if (udiv) { if (three) MI_EVOLVE(false, 3, true); else MI_EVOLVE(false, kMaxSpikes, true); }
         else { if (three) MI_EVOLVE(false, 3, false); else MI_EVOLVE(false, kMaxSpikes, false); }

@@ -187,7 +187,8 @@ MI_HD float div_by(float a, float c)
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (MATH == 1) return a * __builtin_amdgcn_rcpf(c);
     if constexpr (UNI) {
-        if (fabsf(c) >= 0x1.0p-20f && fabsf(c) <= 0x1.0p+20f) {      // (uniform)
+        {   // |c| in [2^-20, 2^20]: checked ONCE on the host before a UNI kernel is launched (uniform_divisors_ok, mi_edm.hip) --
+            // as a test inside the loops the compiler kept it there, two scalar branches per division
             const float rc = 1.0f / c;
             const float q0 = a * rc;
             float q = fmaf(fmaf(-c, q0, a), rc, q0);
