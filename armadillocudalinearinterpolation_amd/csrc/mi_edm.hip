@@ -943,7 +943,9 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
         // Round 4: with its guard down to three integer instructions it also pays at N = 1024 (137.7 -> 134.2 ms at R = 125 000).
         // (edm::div_by<.., true> relies on its divisors -- 1 - beta, beta - 1 and vth - I -- lying in [2^-20, 2^20] in magnitude)
         auto in_range = [](float c) { return fabsf(c) >= 0x1.0p-20f && fabsf(c) <= 0x1.0p+20f; };
-        const bool uniform_divisors_ok = in_range(1.0f - e->p.beta_mean) && in_range(e->p.beta_mean - 1.0f) && in_range(e->p.vth - e->p.I);
+        const float gap = e->p.vth - e->p.I;               // the UNI kernels also take 0 < vth - I <= 1 for granted (edm::will_fire)
+        const bool uniform_divisors_ok = in_range(1.0f - e->p.beta_mean) && in_range(e->p.beta_mean - 1.0f) && in_range(gap) &&
+                                         gap > 0.0f && gap <= 1.0f;
         const bool udiv = MATH == 0 && !hetero && Reff >= cus * 12u && !e->no_uniform_div && uniform_divisors_ok;
         if (hetero) { if (three) MI_EVOLVE(true, 3, false); else MI_EVOLVE(true, kMaxSpikes, false); }
         else if (udiv) { if (three) MI_EVOLVE(false, 3, true); else MI_EVOLVE(false, kMaxSpikes, true); }

@@ -231,11 +231,14 @@ template <int MATH, bool UNI = false, bool FILTER = (MI_EDM_FIRE_FILTER != 0)>
 MI_HD bool will_fire(const Model& M, float v0, float s0, float beta)
 {
     const float gap = M.vth - M.I;
+    // UNI kernels are launched only when the host has found 0 < gap <= 1 (and the uniform divisors in range): the tests on
+    // gap below are then compile-time true -- as run-time tests inside the state pass they were scalar branches per slice.
+    const bool gap_ok = UNI ? true : (gap > 0.0f && gap <= 1.0f);
     // Exact shortcuts: a negative (or NaN) ratio makes log(ratio) NaN, hence pw, thr NaN and `v0 > thr` false.
     // With 0 < gap <= 1 the quotient s0/gap cannot underflow to -0, so s0 < 0 already decides it (no division), and so
     // does a NaN (the poisoned stretch of the lift profile: 3.8 of 16 slices per event at N = 1024); the inhibitory
     // surround puts most of the ring in the first case, 64 contiguous neurons per wave step.
-    if (gap > 0.0f && gap <= 1.0f && !(s0 >= 0.0f)) return false;   // s0 < 0, or NaN: NaN / gap is NaN and fails `ratio >= 0` below
+    if (gap_ok && !(s0 >= 0.0f)) return false;   // s0 < 0, or NaN: NaN / gap is NaN and fails `ratio >= 0` below
 #if defined(__HIP_DEVICE_COMPILE__)
     // EXACT mode, s0 >= 0: the test v0 > thr costs a software log, a software exp and three IEEE divisions (about 86
     // instructions on 3.2 slices per event) and is almost never close.  Evaluate thr first with the hardware transcendentals
@@ -247,21 +250,20 @@ MI_HD bool will_fire(const Model& M, float v0, float s0, float beta)
     // with coefficients bounded by the magnitudes summed in `mag`, so |thr_hw - thr_exact| < 4e-6 mag: a factor 25
     // inside the margin.  tests/test_edm_gpu.py compares the decisions of both forms on dense samples around the
     // threshold (math probe ops 6, 7) and every stage tap of ComputeF with the oracle.
+    // Written without branches (one `decided` flag per lane): as nested ifs the pre-decision was five scalar branches per
+    // slice, and the event loop is bound by those as much as by its vector instructions (profiles/r04_edm_evolve_steps.log).
     if constexpr (MATH == 0 && FILTER) {
-        if (gap > 0.0f && gap <= 1.0f) {                        // (s0 >= 0 here)
+        if (gap_ok) {                                           // (s0 >= 0 here)
             const float rf = s0 * __builtin_amdgcn_rcpf(gap);
             const float ex = __builtin_amdgcn_logf(rf) * __builtin_amdgcn_rcpf(beta);       // log2(ratio) / beta
-            if (rf >= 0x1.0p-40f && rf <= 0x1.0p+40f && fabsf(ex) <= 16.0f) {
-                const float pwf = __builtin_amdgcn_exp2f(ex);
-                const float c = gap * __builtin_amdgcn_rcpf(beta - 1.0f);
-                const float thrf = (M.vth * pwf + M.I * (1.0f - pwf)) - c * (rf - pwf);
-                const float mag = (fabsf(M.vth) * pwf + fabsf(M.I) * (1.0f + pwf)) + fabsf(c) * (rf + pwf);
-                const float margin = 1.0e-4f * mag;
-                if (mag < INFINITY) {
-                    if (v0 > thrf + margin) return true;
-                    if (v0 < thrf - margin) return false;
-                }
-            }
+            const float pwf = __builtin_amdgcn_exp2f(ex);
+            const float c = gap * __builtin_amdgcn_rcpf(beta - 1.0f);
+            const float thrf = (M.vth * pwf + M.I * (1.0f - pwf)) - c * (rf - pwf);
+            const float mag = (fabsf(M.vth) * pwf + fabsf(M.I) * (1.0f + pwf)) + fabsf(c) * (rf + pwf);
+            const float margin = 1.0e-4f * mag;
+            const bool usable = (rf >= 0x1.0p-40f) & (rf <= 0x1.0p+40f) & (fabsf(ex) <= 16.0f) & (mag < INFINITY);   // false for NaN anywhere
+            const bool above = v0 > thrf + margin, below = v0 < thrf - margin;
+            if (usable & (above | below)) return above;
         }
     }
 #endif
