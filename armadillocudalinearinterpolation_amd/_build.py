@@ -16,6 +16,10 @@ HIPCC_FLAGS = [
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-Wall", "-Wno-unused-value",
 ]
+# mi_edm.hip without the SLP vectoriser: it pairs the firing test's independent fp32 operations into v_pk_*_f32, and on
+# gfx950 a packed fp32 instruction takes more issue time than the two it replaces (same bits either way; measured
+# 116.4 -> 113.6 ms at N = 1024, 45.2 -> 43.0 ms at N = 512, profiles/r04_edm_evolve_steps.log).
+PER_SOURCE_FLAGS = {"mi_edm.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -76,7 +80,7 @@ def _build_locked(hipcc, force, verbose):
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     hdr_t = max(os.path.getmtime(p) for p in _deps() if not p.endswith(".hip"))
-    stamp = " ".join(flags)
+    stamp = " ".join(flags) + " " + repr(sorted(PER_SOURCE_FLAGS.items()))
     stamp_path = os.path.join(objdir, "flags.txt")
     same_flags = os.path.exists(stamp_path) and open(stamp_path).read() == stamp
 
@@ -85,7 +89,7 @@ def _build_locked(hipcc, force, verbose):
         if (not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
                 and os.path.getmtime(obj) > hdr_t):
             return obj
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        cmd = [hipcc] + flags + PER_SOURCE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

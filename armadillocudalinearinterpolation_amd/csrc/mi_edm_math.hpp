@@ -198,6 +198,7 @@ MI_HD float div_by(float a, float c)
             const unsigned ex = (__float_as_uint(a) >> 23) & 0xffu;
             const bool in_range = (ex - 27u) <= 200u;
             if (__any(!in_range)) {
+                asm volatile("");       // (a side effect: keeps the compiler from speculating the expansion on every call)
                 const float qi = a / c;
                 q = in_range ? q : qi;
             }
@@ -240,6 +241,7 @@ MI_HD bool will_fire(const Model& M, float v0, float s0, float beta)
     // surround puts most of the ring in the first case, 64 contiguous neurons per wave step.
     if (gap_ok && !(s0 >= 0.0f)) return false;   // s0 < 0, or NaN: NaN / gap is NaN and fails `ratio >= 0` below
 #if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("");       // (a side effect: what follows stays behind the exit above -- the wave skips it when no lane has s0 >= 0)
     // EXACT mode, s0 >= 0: the test v0 > thr costs a software log, a software exp and three IEEE divisions (about 86
     // instructions on 3.2 slices per event) and is almost never close.  Evaluate thr first with the hardware transcendentals
     // (v_rcp_f32, v_log_f32, v_exp_f32: 1 ulp each) and settle every case that is clear of it by 1e-4 of the summed
