@@ -364,19 +364,17 @@ class EventDrivenMap:
         # test / tuning hooks of the Python layer (the library itself reads no environment for this): force an evolve
         # kernel form, switch the exact quotient by launch-uniform divisors off.  Results are bit-identical either way.
         wpr = os.environ.get("MI_EDM_WAVES_PER_REALISATION", "")
-        forms = {"1": 1, "4": 4, "0.5": 2}          # MI_EDM_FORM_WAVE / _WORKGROUP / _TWO_PER_WAVE
-        if wpr in forms or "MI_EDM_NO_UNIFORM_DIV" in os.environ:
-            self.set_kernel_choice(forms.get(wpr, 0), "MI_EDM_NO_UNIFORM_DIV" not in os.environ)
+        if wpr in ("1", "4") or "MI_EDM_NO_UNIFORM_DIV" in os.environ:
+            self.set_kernel_choice(int(wpr) if wpr in ("1", "4") else 0, "MI_EDM_NO_UNIFORM_DIV" not in os.environ)
         if hasattr(ctx, "_children"):
             ctx._children.add(self)
 
     def _push(self):
         check(self._L.mi_edm_set_params(self._h, C.byref(self.params)), self._ctx._h)
 
-    def set_kernel_choice(self, form=0, uniform_division=True):
-        """mi_edm_set_kernel_choice: form 0 (automatic) / 1 (a wave per realisation) / 2 (a wave per two realisations) /
-        4 (a workgroup per realisation), exact quotient by uniform divisors on / off."""
-        check(self._L.mi_edm_set_kernel_choice(self._h, int(form), int(bool(uniform_division))), self._ctx._h)
+    def set_kernel_choice(self, waves_per_realisation=0, uniform_division=True):
+        """mi_edm_set_kernel_choice: 0 / 1 / 4 waves per realisation, exact quotient by uniform divisors on / off."""
+        check(self._L.mi_edm_set_kernel_choice(self._h, int(waves_per_realisation), int(bool(uniform_division))), self._ctx._h)
 
     # setters of EventDrivenMap.hpp:27-51
     def SetTimeHorizon(self, T):

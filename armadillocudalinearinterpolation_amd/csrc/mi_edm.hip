@@ -31,9 +31,6 @@ namespace {
 constexpr int kMaxSpikes = 8;
 constexpr int kMaxGrid = 1024;
 constexpr int kEvolveBlock = 256;   // 4 waves = 4 realisations per workgroup
-#ifndef MI_EVOLVE_DUO
-#define MI_EVOLVE_DUO 1
-#endif
 // Hard bound on events per realisation (mi_edm_params.max_events, default 2^20, at most 2^24): the reference's
 // loop (EventDrivenMap.cu:601) relies on time advancing, which degenerate parameters defeat (a strongly excitatory
 // kernel fires at ever shorter intervals).  Every wave must reach an exit, so the loop also stops after
@@ -206,48 +203,37 @@ __device__ __forceinline__ void wave_argmin(float& best, unsigned& key)
 //       (mi_edm_debug_counters; never what ComputeF launches)
 enum { kTapEvents = 0, kTapMaxEvents, kTapMaxNewton, kTapNewtonCap, kTapEventCap, kTapAccepted, kTapNoFiring, kTapTies, kTapCount };
 // TREE: the block is made of whole warps (N a multiple of 32): arg-min ties as the reference breaks them (tie_key)
-// K: realisations per wave (1 or 2).  K = 2 (EXACT math only): the wave carries TWO realisations side by side in LDS and steps
-//    them event by event together -- the firing-time solves of both (about nine lane pairs each) share ONE Newton round,
-//    the 2 x 3 wave-uniform exponentials share one pass of the software exp, and the two state passes run slice by slice
-//    interleaved (two independent dependency chains per wave).  Each realisation's arithmetic is untouched, so every
-//    result is the bit pattern of the K = 1 kernel.  A realisation that has ended keeps being advanced (harmlessly)
-//    until its partner ends; nothing of it is recorded any more.  The workgroup is 256 / K threads: four realisations
-//    and the same LDS per workgroup either way.
-template <int MATH, bool HETERO, int NS, bool UDIV, bool TAPS = false, bool TREE = true, int K = 1>
-__global__ __launch_bounds__(kEvolveBlock / K) void evolve_kernel(edm::Model M, SpikeSeeds sd, unsigned store,
-                                                                  unsigned long long* __restrict__ taps,
-                                                                  const float* __restrict__ v0,
-                                                                  const float* __restrict__ s0,
-                                                                  const float* __restrict__ w,
-                                                                  float* __restrict__ g_t0,
-                                                                  unsigned short* __restrict__ g_i0,
-                                                                  float* __restrict__ g_t1,
-                                                                  unsigned short* __restrict__ g_i1,
-                                                                  unsigned* __restrict__ g_accept)
+template <int MATH, bool HETERO, int NS, bool UDIV, bool TAPS = false, bool TREE = true>
+__global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, SpikeSeeds sd, unsigned store,
+                                                              unsigned long long* __restrict__ taps,
+                                                              const float* __restrict__ v0,
+                                                              const float* __restrict__ s0,
+                                                              const float* __restrict__ w,
+                                                              float* __restrict__ g_t0,
+                                                              unsigned short* __restrict__ g_i0,
+                                                              float* __restrict__ g_t1,
+                                                              unsigned short* __restrict__ g_i1,
+                                                              unsigned* __restrict__ g_accept)
 {
-    static_assert(K == 1 || (K == 2 && MATH == 0 && !TAPS), "two realisations per wave: EXACT math, no taps");
-    constexpr unsigned kBlock = kEvolveBlock / K, kWaves = kBlock / 64u;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned npl = (M.N + 63u) / 64u;
     const unsigned slots = (unsigned)__builtin_popcount(store) * 64u;
     float* w_lds = lds;
     // homogeneous model: the table holds RN(beta * w[d]), the product every event would otherwise form again
-    for (unsigned i = threadIdx.x; i < (unsigned)kMaxGrid; i += kBlock) {
+    for (unsigned i = threadIdx.x; i < (unsigned)kMaxGrid; i += kEvolveBlock) {
         const float wi = (i < M.N) ? w[i] : 0.0f;
         w_lds[i] = HETERO ? wi : M.beta_mean * wi;
     }
     __syncthreads();
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     constexpr unsigned kArrays = HETERO ? 3u : 2u;
-    const unsigned stride = kArrays * slots;       // floats per realisation
-    // per realisation: the live slices' (v, s) side by side -- slice j holds v at [128 j, 128 j + 64) and s 64 floats further, so that one
-    // ds_read2st64_b32 / ds_write2st64_b32 moves both -- then, for per-neuron beta only, the slices' beta values.
-    // Realisation q of this wave: the same offsets from V + q * stride.
-    float* V = lds + kMaxGrid + (size_t)wave * K * stride;
+    // per wave: the live slices' (v, s) side by side -- slice j holds v at [128 j, 128 j + 64) and s 64 floats further, so that one
+    // ds_read2st64_b32 / ds_write2st64_b32 moves both -- then, for per-neuron beta only, the slices' beta values
+    float* V = lds + kMaxGrid + (size_t)wave * kArrays * slots;
     float* S = V + 64;
     float* B = V + 2u * slots;   // only touched when HETERO; neuron at V[a] has its beta at B[bidx(a)]
     auto bidx = [&](unsigned a) { return ((a - lane) >> 1) + lane; };
-    unsigned* list = reinterpret_cast<unsigned*>(lds + kMaxGrid + (size_t)kWaves * K * stride) + wave * (64u * K);   // this wave's pending neurons
+    unsigned* list = reinterpret_cast<unsigned*>(lds + kMaxGrid + (size_t)(kEvolveBlock / 64) * kArrays * slots) + wave * 64u;   // this wave's pending neurons
     const unsigned full = (1u << M.S) - 1u;
     const float two_T = 2.0f * M.T;
     // arg-min ties as the reference breaks them (tie_key above); blocks that are not whole warps: lowest index
@@ -274,140 +260,105 @@ __global__ __launch_bounds__(kEvolveBlock / K) void evolve_kernel(edm::Model M, 
         }
     }
 
-    const unsigned waves_per_grid = gridDim.x * kWaves;
-    for (unsigned r0 = (blockIdx.x * kWaves + wave) * K; r0 < M.R; r0 += waves_per_grid * K) {
-        bool exists[K];
-#pragma unroll
-        for (int q = 0; q < K; ++q) {
-            exists[q] = r0 + (unsigned)q < M.R;       // (an odd R leaves the last wave's second realisation empty: it starts ended)
+    const unsigned waves_per_grid = gridDim.x * (kEvolveBlock / 64);
+    for (unsigned r = blockIdx.x * (kEvolveBlock / 64) + wave; r < M.R; r += waves_per_grid) {
+        {
             unsigned a = lane;
             for (unsigned m = store; m != 0u; m &= m - 1u, a += 128u) {
                 const unsigned i = (unsigned)__builtin_ctz(m) * 64u + lane;
                 const bool act = i < M.N;
-                V[q * stride + a] = act ? v0[i] : 0.0f;
-                S[q * stride + a] = act ? s0[i] : 0.0f;
-                if constexpr (HETERO)
-                    B[q * stride + bidx(a)] = edm::beta_of<MATH>(M.beta_mean, M.beta_sigma, M.seed, M.N,
-                                                                 (uint64_t)(exists[q] ? r0 + (unsigned)q : r0) + M.real_offset, act ? i : 0u);
+                V[a] = act ? v0[i] : 0.0f;
+                S[a] = act ? s0[i] : 0.0f;
+                if constexpr (HETERO) B[bidx(a)] = edm::beta_of<MATH>(M.beta_mean, M.beta_sigma, M.seed, M.N, (uint64_t)r + M.real_offset, act ? i : 0u);
             }
         }
         // per-bump event slots ([D2]: start at time 0 / index 0); wave-uniform values
-        float lt[K][NS], ct[K][NS], now[K];
-        unsigned li[K][NS], ci[K][NS], crossed[K], events[K];
+        float lt[NS], ct[NS];
+        unsigned li[NS], ci[NS];
+#pragma unroll
+        for (int m = 0; m < NS; ++m) {
+            lt[m] = 0.0f;
+            ct[m] = 0.0f;
+            ci[m] = 0u;
+            li[m] = (m < (int)M.S) ? (unsigned)sd.ind[m] : 0u;
+        }
+        unsigned crossed = 0;
+        float now = 0.0f;
         // Candidate bookkeeping.  Every event needs min over neurons of eventTime().  Neurons that will not
         // fire contribute exactly kNever; the few that will (the bump fronts) need a divergent Newton solve.
         // Instead of running that loop once per 64-neuron slice, each lane records its firing neurons in a
         // bitmask (bit k <-> neuron k*64+lane) during the state pass and the solves then run in compacted
         // rounds: one round handles one pending neuron of EVERY lane.  The minimum is taken lexicographically over
         // (time, largest tie key), so the result does not depend on evaluation order.
-        unsigned base_key[K];         // this lane's non-firing neurons all stand at kNever: the largest tie key among them (~0: none)
-        unsigned pend[K];
-        // the lane's neuron that will not fire and would win a tie among those (all stand at kNever): the highest bit of the
-        // quiet mask (no per-slice tracking); the dead slices' candidate folded in
-        auto lowest_quiet = [&](int q) {
-            const unsigned quiet = ~pend[q] & valid;
-            unsigned bq = quiet != 0u ? lane_base + ((31u - (unsigned)__builtin_clz(quiet)) << key_sh) : ~0u;
-            if (nan_key != ~0u && (bq == ~0u || nan_key > bq)) bq = nan_key;
-            base_key[q] = bq;
-        };
-#pragma unroll
-        for (int q = 0; q < K; ++q) {
-#pragma unroll
-            for (int m = 0; m < NS; ++m) {
-                lt[q][m] = 0.0f;
-                ct[q][m] = 0.0f;
-                ci[q][m] = 0u;
-                li[q][m] = (m < (int)M.S) ? (unsigned)sd.ind[m] : 0u;
-            }
-            crossed[q] = 0u;
-            events[q] = 0u;
-            now[q] = 0.0f;
-            pend[q] = 0u;
+        unsigned base_key = ~0u;      // this lane's non-firing neurons all stand at kNever: the largest tie key among them (~0: none)
+        unsigned pend = 0;
+        {
             unsigned a = lane;
             for (unsigned m = store; m != 0u; m &= m - 1u, a += 128u) {
                 const unsigned k = (unsigned)__builtin_ctz(m);
-                const float bk = HETERO ? B[q * stride + bidx(a)] : M.beta_mean;
-                if (edm::will_fire<MATH, UDIV && !HETERO>(M, V[q * stride + a], S[q * stride + a], bk)) pend[q] |= (1u << pos_of(k));
+                const float bk = HETERO ? B[bidx(a)] : M.beta_mean;
+                if (edm::will_fire<MATH, UDIV && !HETERO>(M, V[a], S[a], bk)) pend |= (1u << pos_of(k));
             }
-            pend[q] &= valid;
-            lowest_quiet(q);
+            pend &= valid;
         }
+        // the lane's neuron that will not fire and would win a tie among those (all stand at kNever): the highest bit of the
+        // quiet mask (no per-slice tracking); the dead slices' candidate folded in
+        auto lowest_quiet = [&]() {
+            const unsigned quiet = ~pend & valid;
+            base_key = quiet != 0u ? lane_base + ((31u - (unsigned)__builtin_clz(quiet)) << key_sh) : ~0u;
+            if (nan_key != ~0u && (base_key == ~0u || nan_key > base_key)) base_key = nan_key;
+        };
+        lowest_quiet();
+        unsigned events = 0;
         unsigned tap_newton = 0, tap_cap = 0, tap_quiet = 0, tap_ties = 0;      // (TAPS only)
-        for (;;) {
-            bool alive[K], any_alive = false;
-#pragma unroll
-            for (int q = 0; q < K; ++q) {
-                alive[q] = exists[q] && crossed[q] < full && now[q] < two_T && events[q] < M.max_events;
-                any_alive = any_alive || alive[q];
-            }
-            if (!any_alive) break;
-            float best[K];
-            unsigned bkey[K];
-#pragma unroll
-            for (int q = 0; q < K; ++q) {
-                if (K > 1 && !alive[q]) pend[q] = 0u;       // an ended realisation asks for no solves
-                events[q] += alive[q] ? 1u : 0u;
-                best[q] = base_key[q] != ~0u ? edm::kNever : INFINITY;
-                bkey[q] = base_key[q];        // (~0 with best = +inf: wave_argmin reads key + 1 = 0 as "no candidate")
-            }
-            // Firing-time solves, one round = the lowest pending neuron of every lane (and realisation).  Which lane solves a
-            // neuron does not matter: the minimum below is lexicographic in (time, tie key).
+        while (crossed < full && now < two_T && events < M.max_events) {
+            ++events;
+            float best = base_key != ~0u ? edm::kNever : INFINITY;
+            unsigned bkey = base_key;         // (~0 with best = +inf: wave_argmin reads key + 1 = 0 as "no candidate")
+            // Firing-time solves, one round = the lowest pending neuron of every lane.  Which lane solves a neuron does not
+            // matter: the minimum below is lexicographic in (time, tie key).
             if constexpr (MATH == 0) {
             // EXACT math: the round's neurons are compacted into `list` (rank by v_mbcnt over the ballot) and each goes to a
             // lane PAIR (j, j + 32) that shares the two software exponentials and the two IEEE divisions of a Newton
             // iteration (edm::newton_time_paired): 138 instead of 149 ms per 125 000 x 1024 ComputeF.
-            for (;;) {
-                unsigned waiting = pend[0];
-#pragma unroll
-                for (int q = 1; q < K; ++q) waiting |= pend[q];
-                if (!__any(waiting != 0u)) break;
-                unsigned total = 0;
-#pragma unroll
-                for (int q = 0; q < K; ++q) {
-                    const bool has = pend[q] != 0u;
-                    const unsigned long long bal = __ballot(has);
-                    if (has) {
-                        const unsigned pos = (unsigned)__builtin_ctz(pend[q]);
-                        pend[q] &= pend[q] - 1u;
-                        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                        // realisation | neuron | its tie key
-                        list[total + rank] = ((unsigned)q << 31) | ((pos_of(pos) * 64u + lane) << 16) | (lane_base + (pos << key_sh));
-                    }
-                    total += (unsigned)__builtin_popcountll(bal);
+            while (__any(pend != 0u)) {
+                const bool has = pend != 0u;
+                const unsigned long long bal = __ballot(has);
+                const unsigned total = (unsigned)__builtin_popcountll(bal);
+                if (has) {
+                    const unsigned pos = (unsigned)__builtin_ctz(pend);
+                    pend &= pend - 1u;
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    list[rank] = ((pos_of(pos) * 64u + lane) << 16) | (lane_base + (pos << key_sh));   // neuron | its tie key
                 }
                 for (unsigned base = 0; base < total; base += 32u) {      // (wave-uniform; more than once only with > 32 solves)
                     const unsigned j = base + (lane & 31u);
                     if (j < total) {
                         const unsigned entry = list[j];
-                        const unsigned q = K > 1 ? entry >> 31 : 0u;
-                        const unsigned i = (entry >> 16) & 0x7fffu, key = entry & 0xffffu;
+                        const unsigned i = entry >> 16, key = entry & 0xffffu;
                         const unsigned k = i >> 6;
                         const unsigned sl = (unsigned)__builtin_popcount(store & ((1u << k) - 1u));
-                        const unsigned a = q * stride + sl * 128u + (i & 63u);
-                        const float bk = HETERO ? B[q * stride + sl * 64u + (i & 63u)] : M.beta_mean;
+                        const unsigned a = sl * 128u + (i & 63u);
+                        const float bk = HETERO ? B[sl * 64u + (i & 63u)] : M.beta_mean;
                         uint32_t it = 0;
                         const float tau = edm::newton_time_paired<MATH, UDIV && !HETERO>(M, V[a], S[a], bk, lane >= 32u, TAPS ? &it : nullptr);
                         if (lane < 32u) {
                             if constexpr (TAPS) {
                                 tap_newton = max(tap_newton, it);
                                 tap_cap += (it >= M.max_iter) ? 1u : 0u;
-                                tap_ties += (tau == best[0] && tau < edm::kNever) ? 1u : 0u;      // two firing neurons met in one lane
+                                tap_ties += (tau == best && tau < edm::kNever) ? 1u : 0u;      // two firing neurons met in one lane
                             }
-#pragma unroll
-                            for (int qq = 0; qq < K; ++qq) {
-                                const bool mine = K == 1 || q == (unsigned)qq;
-                                if (mine && (tau < best[qq] || (tau == best[qq] && key > bkey[qq]))) { best[qq] = tau; bkey[qq] = key; }
-                            }
+                            if (tau < best || (tau == best && key > bkey)) { best = tau; bkey = key; }
                         }
                     }
                 }
             }
             } else {
             // FAST math (hardware exp and reciprocal: nothing worth sharing, the pairing costs 10 %): every lane solves its own
-            while (__any(pend[0] != 0u)) {
-                if (pend[0] != 0u) {
-                    const unsigned pos = (unsigned)__builtin_ctz(pend[0]);
-                    pend[0] &= pend[0] - 1u;
+            while (__any(pend != 0u)) {
+                if (pend != 0u) {
+                    const unsigned pos = (unsigned)__builtin_ctz(pend);
+                    pend &= pend - 1u;
                     const unsigned k = pos_of(pos);
                     const unsigned a = (unsigned)__builtin_popcount(store & ((1u << k) - 1u)) * 128u + lane;
                     const float bk = HETERO ? B[bidx(a)] : M.beta_mean;
@@ -416,156 +367,110 @@ __global__ __launch_bounds__(kEvolveBlock / K) void evolve_kernel(edm::Model M, 
                     if constexpr (TAPS) {
                         tap_newton = max(tap_newton, it);
                         tap_cap += (it >= M.max_iter) ? 1u : 0u;
-                        tap_ties += (tau == best[0] && tau < edm::kNever) ? 1u : 0u;
+                        tap_ties += (tau == best && tau < edm::kNever) ? 1u : 0u;
                     }
                     const unsigned key = lane_base + (pos << key_sh);
-                    if (tau < best[0] || (tau == best[0] && key > bkey[0])) { best[0] = tau; bkey[0] = key; }
+                    if (tau < best || (tau == best && key > bkey)) { best = tau; bkey = key; }
                 }
             }
             }
             if constexpr (TAPS) {
-                const float mine = best[0];
-                float bb = best[0];
-                unsigned kk = bkey[0];
+                const float mine = best;
+                float bb = best;
+                unsigned kk = bkey;
                 wave_argmin(bb, kk);
                 if (bb >= edm::kNever) tap_quiet += 1u;
                 else if (__builtin_popcountll(__ballot(mine == bb)) > 1) tap_ties += 1u;   // ... or of two lanes
             }
+            wave_argmin(best, bkey);
             // the winner is the same in every lane: in scalar registers the event bookkeeping below (nearest bump,
             // crossed mask) runs on the scalar unit
-            unsigned idx[K];
-            float dt[K];
-#pragma unroll
-            for (int q = 0; q < K; ++q) {
-                wave_argmin(best[q], bkey[q]);
-                idx[q] = tie_key_neuron((unsigned)__builtin_amdgcn_readfirstlane((int)bkey[q]), tree);
-                dt[q] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, best[q])));
-                if (padded && !(dt[q] < edm::kNever)) {       // no neuron fires before "never": the padding pair (100.0f, 0) wins (:867-868)
-                    dt[q] = edm::kNever;
-                    idx[q] = 0u;
-                }
-                if (K > 1 && !alive[q]) {                     // ended: any in-range winner will do (nothing of it is recorded)
-                    dt[q] = edm::kNever;
-                    idx[q] = 0u;
-                }
+            unsigned idx = tie_key_neuron((unsigned)__builtin_amdgcn_readfirstlane((int)bkey), tree);
+            float dt = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, best)));
+            if (padded && !(dt < edm::kNever)) {       // no neuron fires before "never": the padding pair (100.0f, 0) wins (:867-868)
+                dt = edm::kNever;
+                idx = 0u;
             }
             // analytic state advance (EventDrivenMap.cu:612-617), fused with the firing test for the NEXT event
-            float e1[K], e2u[K], e3u[K];
+            float e1, e2u = 0.0f, e3u = 0.0f;
             if constexpr (!HETERO) {
-                // the three wave-uniform exponentials of the advance (per realisation) in ONE pass of the software exp: lanes
-                // 3q, 3q + 1, 3q + 2 take realisation q's three arguments, the results come back through v_readlane (same routine,
-                // same inputs: same bits)
-                float dtl = dt[0];
-                unsigned role = lane;
-#pragma unroll
-                for (int q = 1; q < K; ++q) {
-                    dtl = (lane >= 3u * (unsigned)q) ? dt[q] : dtl;
-                    role = (lane >= 3u * (unsigned)q) ? lane - 3u * (unsigned)q : role;
-                }
-                const float arg = (role == 1u) ? (1.0f - M.beta_mean) * dtl : (role == 2u) ? -M.beta_mean * dtl : -dtl;
+                // the three wave-uniform exponentials of the advance in ONE pass of the software exp: lanes 0, 1, 2 take the
+                // three arguments, the results come back through v_readlane (same routine, same inputs: same bits)
+                const float arg = (lane == 1u) ? (1.0f - M.beta_mean) * dt : (lane == 2u) ? -M.beta_mean * dt : -dt;
                 const float ex = edm::expf_<MATH>(arg);
-#pragma unroll
-                for (int q = 0; q < K; ++q) {
-                    e1[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ex), 3 * q));
-                    e2u[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ex), 3 * q + 1));
-                    e3u[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ex), 3 * q + 2));
-                }
+                e1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ex), 0));
+                e2u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ex), 1));
+                e3u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ex), 2));
             } else {
-#pragma unroll
-                for (int q = 0; q < K; ++q) {
-                    e1[q] = edm::expf_<MATH>(-dt[q]);
-                    e2u[q] = e3u[q] = 0.0f;
-                }
+                e1 = edm::expf_<MATH>(-dt);
             }
             unsigned a = lane;
 #pragma unroll 1                                                            // rolled: measured (DESIGN_HISTORY.md section 4)
             for (unsigned m = store; m != 0u; m &= m - 1u, a += 128u) {      // live slices only
                 const unsigned k = (unsigned)__builtin_ctz(m);
                 const unsigned i = k * 64u + lane;
-                float bk[K], so[K], vo[K], wd[K], vv[K], sn[K];
-#pragma unroll
-                for (int q = 0; q < K; ++q) {                                // every LDS read of the slice first (K = 2: both realisations')
-                    bk[q] = HETERO ? B[q * stride + bidx(a)] : M.beta_mean;
-                    so[q] = S[q * stride + a];
-                    vo[q] = V[q * stride + a];
-                    unsigned dist;                                           // |i - idx| < kMaxGrid: i < npl*64 <= kMaxGrid, idx < N
-                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dist) : "v"(i), "s"(idx[q]));
-                    wd[q] = w_lds[dist];
+                const float bk = HETERO ? B[bidx(a)] : M.beta_mean;
+                const float e2 = HETERO ? edm::expf_<MATH>((1.0f - bk) * dt) : e2u;
+                const float e3 = HETERO ? edm::expf_<MATH>(-bk * dt) : e3u;
+                const float so = S[a];
+                unsigned dist;                                            // |i - idx| < kMaxGrid: i < npl*64 <= kMaxGrid, idx < N
+                asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dist) : "v"(i), "s"(idx));
+                const float wd = w_lds[dist];                             // (every LDS read of the slice before its arithmetic)
+                float vv = V[a] * e1;
+                vv = vv + (M.I * (1.0f - e1) + edm::div_by<MATH, UDIV && !HETERO>(so * e1, 1.0f - bk) * (e2 - 1.0f));
+                // reset of the neuron that fired (:615 multiplies every v by (tid != index)): x * 1 == x, so only that
+                // neuron needs the multiply (by 0: NaN stays NaN, a finite value becomes a signed zero) -- and only its
+                // slice looks for it (a scalar branch: idx and k are wave-uniform)
+                if (k == (idx >> 6)) {
+                    asm volatile("" : "+v"(vv));      // (keeps the compiler from turning the branch into a select on every slice)
+                    vv = (lane == (idx & 63u)) ? vv * 0.0f : vv;
                 }
-#pragma unroll
-                for (int q = 0; q < K; ++q) {
-                    const float e2 = HETERO ? edm::expf_<MATH>((1.0f - bk[q]) * dt[q]) : e2u[q];
-                    const float e3 = HETERO ? edm::expf_<MATH>(-bk[q] * dt[q]) : e3u[q];
-                    float x = vo[q] * e1[q];
-                    x = x + (M.I * (1.0f - e1[q]) + edm::div_by<MATH, UDIV && !HETERO>(so[q] * e1[q], 1.0f - bk[q]) * (e2 - 1.0f));
-                    // reset of the neuron that fired (:615 multiplies every v by (tid != index)): x * 1 == x, so only that
-                    // neuron needs the multiply (by 0: NaN stays NaN, a finite value becomes a signed zero) -- and only its
-                    // slice looks for it (a scalar branch: idx and k are wave-uniform)
-                    if (k == (idx[q] >> 6)) {
-                        asm volatile("" : "+v"(x));      // (keeps the compiler from turning the branch into a select on every slice)
-                        x = (lane == (idx[q] & 63u)) ? x * 0.0f : x;
-                    }
-                    vv[q] = x;
-                    sn[q] = so[q] * e3 + (HETERO ? bk[q] * wd[q] : wd[q]);
-                }
-#pragma unroll
-                for (int q = 0; q < K; ++q) {
-                    V[q * stride + a] = vv[q];
-                    S[q * stride + a] = sn[q];
-                }
-#pragma unroll
-                for (int q = 0; q < K; ++q)
-                    pend[q] |= (edm::will_fire<MATH, UDIV && !HETERO>(M, vv[q], sn[q], bk[q]) ? 1u : 0u) << pos_of(k);   // (padding lanes: masked below)
+                float sn = so * e3;
+                sn = sn + (HETERO ? bk * wd : wd);
+                V[a] = vv;
+                S[a] = sn;
+                pend |= (edm::will_fire<MATH, UDIV && !HETERO>(M, vv, sn, bk) ? 1u : 0u) << pos_of(k);   // (padding lanes: masked below)
             }
+            pend &= valid;
+            lowest_quiet();
+            now = now + dt;
+            // which bump does the event belong to ([D3]: the reference's increment rule, :625-629)
+            unsigned mi = 0;
 #pragma unroll
-            for (int q = 0; q < K; ++q) {
-                pend[q] &= valid;
-                lowest_quiet(q);
-                if (K > 1 && !alive[q]) continue;
-                now[q] = now[q] + dt[q];
-                // which bump does the event belong to ([D3]: the reference's increment rule, :625-629)
-                unsigned mi = 0;
+            for (int m = 1; m < NS; ++m) {
+                if (m < (int)M.S) {
+                    unsigned lmi = li[0];
 #pragma unroll
-                for (int m = 1; m < NS; ++m) {
-                    if (m < (int)M.S) {
-                        unsigned lmi = li[q][0];
+                    for (int j = 1; j < NS; ++j) lmi = (mi == (unsigned)j) ? li[j] : lmi;
+                    const int dm = abs((int)idx - (int)li[m]);
+                    const int d0 = abs((int)idx - (int)lmi);
+                    mi += (dm < d0) ? 1u : 0u;
+                }
+            }
+            if (!(crossed & (1u << mi))) {
+                const bool after = now > M.T;
 #pragma unroll
-                        for (int j = 1; j < NS; ++j) lmi = (mi == (unsigned)j) ? li[q][j] : lmi;
-                        const int dm = abs((int)idx[q] - (int)li[q][m]);
-                        const int d0 = abs((int)idx[q] - (int)lmi);
-                        mi += (dm < d0) ? 1u : 0u;
+                for (int m = 0; m < NS; ++m) {
+                    if (mi == (unsigned)m) {
+                        if (after) { ct[m] = now; ci[m] = idx; }
+                        else { lt[m] = now; li[m] = idx; }
                     }
                 }
-                if (!(crossed[q] & (1u << mi))) {
-                    const bool after = now[q] > M.T;
-#pragma unroll
-                    for (int m = 0; m < NS; ++m) {
-                        if (mi == (unsigned)m) {
-                            if (after) { ct[q][m] = now[q]; ci[q][m] = idx[q]; }
-                            else { lt[q][m] = now[q]; li[q][m] = idx[q]; }
-                        }
-                    }
-                    if (after) crossed[q] += (1u << mi);
-                }
+                if (after) crossed += (1u << mi);
             }
         }
         // [spike][realisation] layout, EventDrivenMap.cu:661-668
 #pragma unroll
-        for (int q = 0; q < K; ++q) {
-            if (!exists[q]) continue;
-            const unsigned r = r0 + (unsigned)q;
-#pragma unroll
-            for (int m = 0; m < NS; ++m) {
-                if (lane == (unsigned)m && m < (int)M.S) {
-                    const size_t k = (size_t)m * M.R + r;
-                    g_t0[k] = lt[q][m];
-                    g_i0[k] = (unsigned short)li[q][m];
-                    g_t1[k] = ct[q][m];
-                    g_i1[k] = (unsigned short)ci[q][m];
-                }
+        for (int m = 0; m < NS; ++m) {
+            if (lane == (unsigned)m && m < (int)M.S) {
+                const size_t k = (size_t)m * M.R + r;
+                g_t0[k] = lt[m];
+                g_i0[k] = (unsigned short)li[m];
+                g_t1[k] = ct[m];
+                g_i1[k] = (unsigned short)ci[m];
             }
-            if (lane == 0) g_accept[r] = (crossed[q] == full) ? 1u : 0u;
         }
+        if (lane == 0) g_accept[r] = (crossed == full) ? 1u : 0u;
         if constexpr (TAPS) {
             unsigned mx = tap_newton, cap = tap_cap, ties = tap_ties;
             for (int off = 32; off > 0; off >>= 1) {
@@ -574,12 +479,12 @@ __global__ __launch_bounds__(kEvolveBlock / K) void evolve_kernel(edm::Model M, 
                 ties = max(ties, (unsigned)__shfl_xor((int)ties, off));
             }
             if (lane == 0) {
-                atomicAdd(&taps[kTapEvents], (unsigned long long)events[0]);
-                atomicMax(&taps[kTapMaxEvents], (unsigned long long)events[0]);
+                atomicAdd(&taps[kTapEvents], (unsigned long long)events);
+                atomicMax(&taps[kTapMaxEvents], (unsigned long long)events);
                 atomicMax(&taps[kTapMaxNewton], (unsigned long long)mx);
                 atomicAdd(&taps[kTapNewtonCap], (unsigned long long)cap);
-                atomicAdd(&taps[kTapEventCap], (crossed[0] < full && events[0] >= M.max_events) ? 1ull : 0ull);
-                atomicAdd(&taps[kTapAccepted], (crossed[0] == full) ? 1ull : 0ull);
+                atomicAdd(&taps[kTapEventCap], (crossed < full && events >= M.max_events) ? 1ull : 0ull);
+                atomicAdd(&taps[kTapAccepted], (crossed == full) ? 1ull : 0ull);
                 atomicAdd(&taps[kTapNoFiring], (unsigned long long)tap_quiet);
                 atomicAdd(&taps[kTapTies], (unsigned long long)ties);
             }
@@ -860,7 +765,7 @@ struct mi_edm {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};
     // test / tuning knobs (mi_edm_set_kernel_choice); every choice gives bit-identical results
-    int kernel_form = MI_EDM_FORM_AUTO;   // MI_EDM_FORM_*: forces an evolve kernel form (AUTO: by realisation count)
+    int waves_per_real = 0;            // 1 | 4 forces an evolve kernel form (0: by realisation count)
     bool no_uniform_div = false;       // never take the exact quotient by wave-uniform divisors
 };
 
@@ -985,8 +890,7 @@ int evolve_form(const mi_edm* e)
     const bool hetero = e->p.beta_stddev != 0.0f;
     const bool dedup = e->p.dedup_identical != 0 && !hetero && e->p.n_real > 1;
     const unsigned Reff = dedup ? 1u : e->p.n_real;
-    if (e->kernel_form != MI_EDM_FORM_AUTO) return e->kernel_form == MI_EDM_FORM_WORKGROUP ? 4 : 1;
-    return (Reff < kWgNarrow) ? 4 : 1;
+    return e->waves_per_real ? e->waves_per_real : ((Reff < kWgNarrow) ? 4 : 1);
 }
 
 // live: the lift kernel's live-slice mask (wave-per-realisation form only; ignored by the latency form)
@@ -1026,25 +930,14 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
     if (wpr == 1) {
     // (N not a multiple of 32 -- no launch the reference could make -- runs the !TREE instantiation: ties to the lowest index)
     const bool whole_warps = (N & 31u) == 0u;
-#define MI_EVOLVE_K(H, NS, UD, KK)                                                                                \
-    do {                                                                                                          \
-        if (whole_warps)                                                                                          \
-            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, UD, false, true, KK>), dim3(blocks), dim3(kEvolveBlock / KK), lds_bytes, \
-                               ctx->stream, M, sd, live, nullptr, e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept); \
-        else                                                                                                      \
-            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, false, false, false, KK>), dim3(blocks), dim3(kEvolveBlock / KK), lds_bytes, \
-                               ctx->stream, M, sd, live, nullptr, e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept); \
-    } while (0)
-        // Two realisations per wave (template parameter K of evolve_kernel) once the launch brings several waves per SIMD:
-        // EXACT math only (the shared Newton round is what it saves).
-        const bool duo = MATH == 0 && (e->kernel_form == MI_EDM_FORM_TWO_PER_WAVE ||
-                                       (e->kernel_form == MI_EDM_FORM_AUTO && MI_EVOLVE_DUO && Reff >= cus * 12u));
 #define MI_EVOLVE(H, NS, UD)                                                                                      \
     do {                                                                                                          \
-        if constexpr (MATH == 0) {                                                                                \
-            if (duo) { MI_EVOLVE_K(H, NS, UD, 2); break; }                                                        \
-        }                                                                                                         \
-        MI_EVOLVE_K(H, NS, UD, 1);                                                                                \
+        if (whole_warps)                                                                                          \
+            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, UD, false, true>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
+                               M, sd, live, nullptr, e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept);             \
+        else                                                                                                      \
+            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, false, false, false>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
+                               M, sd, live, nullptr, e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept);             \
     } while (0)
         // The exact quotient by uniform divisors (edm::div_by) pays once the launch brings three or more waves per SIMD
         // (N = 512: R = 16384 10.25 -> 9.00 ms, R = 4000 3.10 -> 2.91 ms, but R = 1000 -- one wave per SIMD -- 1.59 -> 2.10 ms).
@@ -1059,7 +952,6 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
         else if (udiv) { if (three) MI_EVOLVE(false, 3, true); else MI_EVOLVE(false, kMaxSpikes, true); }
         else { if (three) MI_EVOLVE(false, 3, false); else MI_EVOLVE(false, kMaxSpikes, false); }
 #undef MI_EVOLVE
-#undef MI_EVOLVE_K
     } else {
         const unsigned bt = 64u * (unsigned)wpr;
         (void)live;
@@ -1219,13 +1111,13 @@ mi_status mi_edm_set_params(mi_edm* e, const mi_edm_params* p)
     return ensure_buffers(e);
 }
 
-mi_status mi_edm_set_kernel_choice(mi_edm* e, int form, int uniform_division)
+mi_status mi_edm_set_kernel_choice(mi_edm* e, int waves_per_realisation, int uniform_division)
 {
     MI_REQUIRE(nullptr, e != nullptr, "mi_edm_set_kernel_choice: handle is NULL");
-    MI_REQUIRE(e->ctx, form == MI_EDM_FORM_AUTO || form == MI_EDM_FORM_WAVE || form == MI_EDM_FORM_TWO_PER_WAVE || form == MI_EDM_FORM_WORKGROUP,
-               "mi_edm_set_kernel_choice: form must be one of MI_EDM_FORM_AUTO / _WAVE / _TWO_PER_WAVE / _WORKGROUP");
+    MI_REQUIRE(e->ctx, waves_per_realisation == 0 || waves_per_realisation == 1 || waves_per_realisation == 4,
+               "mi_edm_set_kernel_choice: waves_per_realisation must be 0 (automatic), 1 or 4");
     MI_REQUIRE(e->ctx, !e->pending, "mi_edm_set_kernel_choice: an evaluation is in flight");
-    e->kernel_form = form;
+    e->waves_per_real = waves_per_realisation;
     e->no_uniform_div = uniform_division == 0;
     return MI_OK;
 }

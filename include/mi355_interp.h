@@ -260,16 +260,10 @@ mi_status mi_edm_destroy(mi_edm* e);
 /* setters of EventDrivenMap.hpp:27-51 arrive as a new parameter block */
 mi_status mi_edm_set_params(mi_edm* e, const mi_edm_params* p);
 /* Tuning / test knob; every choice gives bit-identical results (tests/test_edm_gpu.py runs each case under all of them).
- * form: MI_EDM_FORM_AUTO = by realisation count (default: a workgroup of four waves per realisation below 600
- * realisations, one wave per realisation from there, one wave per TWO realisations -- EXACT math only -- once the launch
- * fills the device several times over), any other MI_EDM_FORM_* = that form always (TWO_PER_WAVE with FAST math runs
- * WAVE).  uniform_division: 1 (default) = the five-operation exact quotient where a divisor is the same for the whole
- * launch, 0 = IEEE division everywhere. */
-#define MI_EDM_FORM_AUTO         0
-#define MI_EDM_FORM_WAVE         1   /* one wave64 per realisation                                   */
-#define MI_EDM_FORM_TWO_PER_WAVE 2   /* one wave64 per two realisations: their firing-time solves share a Newton round */
-#define MI_EDM_FORM_WORKGROUP    4   /* four waves per realisation (latency form)                    */
-mi_status mi_edm_set_kernel_choice(mi_edm* e, int form, int uniform_division);
+ * waves_per_realisation: 0 = by realisation count (default: a workgroup of four waves per realisation below 600
+ * realisations, one wave per realisation from there), 1 or 4 = that form always.  uniform_division: 1 (default) = the
+ * five-operation exact quotient where a divisor is the same for the whole launch, 0 = IEEE division everywhere. */
+mi_status mi_edm_set_kernel_choice(mi_edm* e, int waves_per_realisation, int uniform_division);
 /* ComputeF (EventDrivenMap.cu:154-240).  z: host, n_spikes doubles (c, Z1..);
  * f: host, n_spikes doubles.  partial (optional, may be NULL): host,
  * MI_EDM_PARTIAL_LEN(n_spikes) doubles receiving this device's partial block

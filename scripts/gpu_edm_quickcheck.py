@@ -14,7 +14,7 @@ import oracle  # noqa: E402
 
 Z = [0.3310, 0.6914, 1.3557]
 ctx = mi.Context(0)
-for form in ("0.5", "4", "1"):
+for form in ("4", "1"):
     os.environ["MI_EDM_WAVES_PER_REALISATION"] = form
     for kw in (dict(n_grid=64, n_real=4), dict(n_grid=512, n_real=5), dict(n_grid=1024, n_real=8), dict(n_grid=1000, n_real=3),
                dict(n_grid=1024, n_real=5, beta_stddev=0.3, seed=7), dict(n_grid=512, n_real=3500)):

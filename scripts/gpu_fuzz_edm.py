@@ -31,7 +31,7 @@ def run(budget, seed, ctx=None):
         )
         c = rng.uniform(0.2, 0.5)
         Z = np.concatenate([[c], np.sort(rng.uniform(0.3, 2.5, S - 1))]) if S > 1 else np.array([c])
-        os.environ["MI_EDM_WAVES_PER_REALISATION"] = str(rng.choice(["1", "0.5", "0.5", "4"]))   # (0.5: a wave per TWO realisations)
+        os.environ["MI_EDM_WAVES_PER_REALISATION"] = str(rng.choice([1, 4]))
         edm = mi.EventDrivenMap(ctx, [kw.pop("beta_mean")], kw.pop("n_real"), **kw)
         f, partial = edm.ComputeF(Z, want_partial=True)
         dbg = edm.debug_read()

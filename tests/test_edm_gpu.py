@@ -13,17 +13,15 @@ pytestmark = pytest.mark.gpu
 Z_DRIVER = [0.3310, 0.6914, 1.3557]
 
 
-@pytest.fixture(autouse=True, params=["auto", "wave_per_realisation", "wave_per_two_realisations", "workgroup_per_realisation"])
+@pytest.fixture(autouse=True, params=["auto", "wave_per_realisation", "workgroup_per_realisation"])
 def evolve_form(request, monkeypatch):
-    """The evolve kernel has three forms (one wave per realisation, one wave per TWO realisations -- EXACT math --, or a
-    workgroup of four waves per realisation) chosen by the realisation count; every test of this file runs with the
-    automatic choice and with each form forced (MI_EDM_WAVES_PER_REALISATION, read when an EventDrivenMap handle is
-    created), so all are held to the same bit-exact parity."""
+    """The evolve kernel has two forms (one wave, or a workgroup of four waves, per realisation) chosen by the
+    realisation count; every test of this file runs with the automatic choice and with each form forced
+    (MI_EDM_WAVES_PER_REALISATION, read when an EventDrivenMap handle is created), so both are held to the same bit-exact parity."""
     if request.param == "auto":
         monkeypatch.delenv("MI_EDM_WAVES_PER_REALISATION", raising=False)
     else:
-        monkeypatch.setenv("MI_EDM_WAVES_PER_REALISATION", {"wave_per_realisation": "1", "wave_per_two_realisations": "0.5",
-                                                            "workgroup_per_realisation": "4"}[request.param])
+        monkeypatch.setenv("MI_EDM_WAVES_PER_REALISATION", "1" if request.param == "wave_per_realisation" else "4")
     return request.param
 
 
