@@ -177,7 +177,11 @@ __device__ __forceinline__ void wave_argmin(float& best, unsigned& key)
 {
     const unsigned tb = __float_as_uint(best);
     const unsigned tmin = wave_umin(tb);
-    key = wave_umax(tb == tmin ? key + 1u : 0u) - 1u;
+    const unsigned long long at_min = __ballot(tb == tmin);
+    if (__builtin_popcountll(at_min) == 1)      // one lane holds the minimum (a firing time: every event in practice): its key, no second reduction
+        key = (unsigned)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(at_min));
+    else
+        key = wave_umax(tb == tmin ? key + 1u : 0u) - 1u;
     best = __uint_as_float(tmin);
 }
 
@@ -203,7 +207,8 @@ __device__ __forceinline__ void wave_argmin(float& best, unsigned& key)
 //       (mi_edm_debug_counters; never what ComputeF launches)
 enum { kTapEvents = 0, kTapMaxEvents, kTapMaxNewton, kTapNewtonCap, kTapEventCap, kTapAccepted, kTapNoFiring, kTapTies, kTapCount };
 // TREE: the block is made of whole warps (N a multiple of 32): arg-min ties as the reference breaks them (tie_key)
-template <int MATH, bool HETERO, int NS, bool UDIV, bool TAPS = false, bool TREE = true>
+// GAP: the host has checked 0 < vth - I <= 1 (edm::gap_settles_sign; UDIV implies it)
+template <int MATH, bool HETERO, int NS, bool UDIV, bool TAPS = false, bool TREE = true, bool GAP = UDIV>
 __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, SpikeSeeds sd, unsigned store,
                                                               unsigned long long* __restrict__ taps,
                                                               const float* __restrict__ v0,
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             for (unsigned m = store; m != 0u; m &= m - 1u, a += 128u) {
                 const unsigned k = (unsigned)__builtin_ctz(m);
                 const float bk = HETERO ? B[bidx(a)] : M.beta_mean;
-                if (edm::will_fire<MATH, UDIV && !HETERO>(M, V[a], S[a], bk)) pend |= (1u << pos_of(k));
+                if (edm::will_fire<MATH, UDIV && !HETERO, (MI_EDM_FIRE_FILTER != 0), GAP>(M, V[a], S[a], bk)) pend |= (1u << pos_of(k));
             }
             pend &= valid;
         }
@@ -405,17 +410,22 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 e1 = edm::expf_<MATH>(-dt);
             }
             unsigned a = lane;
+            const unsigned lane4 = lane * 4u, idx4 = idx * 4u;
+            const bool sign_settles = edm::gap_settles_sign<GAP>(M);
+            typedef __attribute__((address_space(3))) const float lds_cfloat;
+            const unsigned w_base = (unsigned)(uintptr_t)(lds_cfloat*)w_lds;
 #pragma unroll 1                                                            // rolled: measured (DESIGN_HISTORY.md section 4)
             for (unsigned m = store; m != 0u; m &= m - 1u, a += 128u) {      // live slices only
                 const unsigned k = (unsigned)__builtin_ctz(m);
-                const unsigned i = k * 64u + lane;
                 const float bk = HETERO ? B[bidx(a)] : M.beta_mean;
                 const float e2 = HETERO ? edm::expf_<MATH>((1.0f - bk) * dt) : e2u;
                 const float e3 = HETERO ? edm::expf_<MATH>(-bk * dt) : e3u;
                 const float so = S[a];
-                unsigned dist;                                            // |i - idx| < kMaxGrid: i < npl*64 <= kMaxGrid, idx < N
-                asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dist) : "v"(i), "s"(idx));
-                const float wd = w_lds[dist];                             // (every LDS read of the slice before its arithmetic)
+                // the coupling value w[|i - idx|] (|i - idx| < kMaxGrid: i < npl*64 <= kMaxGrid, idx < N), addressed in bytes:
+                // 4 |i - idx| = |4 i - 4 idx| in one v_sad_u32.  (Every LDS read of the slice before its arithmetic.)
+                unsigned w_at;                                            // LDS address: the table's own goes in as v_sad_u32's addend
+                asm("v_sad_u32 %0, %1, %2, %3" : "=v"(w_at) : "v"((k << 8) | lane4), "s"(idx4), "v"(w_base));
+                const float wd = *reinterpret_cast<lds_cfloat*>((uintptr_t)w_at);
                 float vv = V[a] * e1;
                 vv = vv + (M.I * (1.0f - e1) + edm::div_by<MATH, UDIV && !HETERO>(so * e1, 1.0f - bk) * (e2 - 1.0f));
                 // reset of the neuron that fired (:615 multiplies every v by (tid != index)): x * 1 == x, so only that
@@ -429,7 +439,11 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 sn = sn + (HETERO ? bk * wd : wd);
                 V[a] = vv;
                 S[a] = sn;
-                pend |= (edm::will_fire<MATH, UDIV && !HETERO>(M, vv, sn, bk) ? 1u : 0u) << pos_of(k);   // (padding lanes: masked below)
+                // With 0 < vth - I <= 1 no lane of the slice can fire unless some s is >= 0 (will_fire's first exit): most slices
+                // of most events leave here with one scalar branch -- inside will_fire the same exit costs an exec-mask save /
+                // restore and the two instructions that fold an all-false result into pend.
+                if (!sign_settles || __any(sn >= 0.0f))
+                pend |= (edm::will_fire<MATH, UDIV && !HETERO, (MI_EDM_FIRE_FILTER != 0), GAP>(M, vv, sn, bk) ? 1u : 0u) << pos_of(k);   // (padding lanes: masked below)
             }
             pend &= valid;
             lowest_quiet();
@@ -930,28 +944,35 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
     if (wpr == 1) {
     // (N not a multiple of 32 -- no launch the reference could make -- runs the !TREE instantiation: ties to the lowest index)
     const bool whole_warps = (N & 31u) == 0u;
-#define MI_EVOLVE(H, NS, UD)                                                                                      \
+#define MI_EVOLVE_G(H, NS, UD, G)                                                                                 \
     do {                                                                                                          \
         if (whole_warps)                                                                                          \
-            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, UD, false, true>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
+            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, UD, false, true, G>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
                                M, sd, live, nullptr, e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept);             \
         else                                                                                                      \
-            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, false, false, false>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
+            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, false, false, false, G>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
                                M, sd, live, nullptr, e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept);             \
+    } while (0)
+    // (UD is only ever true together with gap_ok)
+#define MI_EVOLVE(H, NS, UD)                                                                                      \
+    do {                                                                                                          \
+        if (gap_ok) MI_EVOLVE_G(H, NS, UD, true);                                                                 \
+        else MI_EVOLVE_G(H, NS, false, false);                                                                    \
     } while (0)
         // The exact quotient by uniform divisors (edm::div_by) pays once the launch brings three or more waves per SIMD
         // (N = 512: R = 16384 10.25 -> 9.00 ms, R = 4000 3.10 -> 2.91 ms, but R = 1000 -- one wave per SIMD -- 1.59 -> 2.10 ms).
         // Round 4: with its guard down to three integer instructions it also pays at N = 1024 (137.7 -> 134.2 ms at R = 125 000).
         // (edm::div_by<.., true> relies on its divisors -- 1 - beta, beta - 1 and vth - I -- lying in [2^-20, 2^20] in magnitude)
         auto in_range = [](float c) { return fabsf(c) >= 0x1.0p-20f && fabsf(c) <= 0x1.0p+20f; };
-        const float gap = e->p.vth - e->p.I;               // the UNI kernels also take 0 < vth - I <= 1 for granted (edm::will_fire)
-        const bool uniform_divisors_ok = in_range(1.0f - e->p.beta_mean) && in_range(e->p.beta_mean - 1.0f) && in_range(gap) &&
-                                         gap > 0.0f && gap <= 1.0f;
+        const float gap = e->p.vth - e->p.I;               // 0 < vth - I <= 1 (edm::gap_settles_sign): a template flag of the kernels
+        const bool gap_ok = gap > 0.0f && gap <= 1.0f;
+        const bool uniform_divisors_ok = in_range(1.0f - e->p.beta_mean) && in_range(e->p.beta_mean - 1.0f) && in_range(gap) && gap_ok;
         const bool udiv = MATH == 0 && !hetero && Reff >= cus * 12u && !e->no_uniform_div && uniform_divisors_ok;
         if (hetero) { if (three) MI_EVOLVE(true, 3, false); else MI_EVOLVE(true, kMaxSpikes, false); }
         else if (udiv) { if (three) MI_EVOLVE(false, 3, true); else MI_EVOLVE(false, kMaxSpikes, true); }
         else { if (three) MI_EVOLVE(false, 3, false); else MI_EVOLVE(false, kMaxSpikes, false); }
 #undef MI_EVOLVE
+#undef MI_EVOLVE_G
     } else {
         const unsigned bt = 64u * (unsigned)wpr;
         (void)live;

@@ -193,10 +193,10 @@ MI_HD float div_by(float a, float c)
             const float q0 = a * rc;
             float q = fmaf(fmaf(-c, q0, a), rc, q0);
             q = fmaf(fmaf(-c, q, a), rc, q);
-            // biased exponent of a in [27, 227], i.e. |a| in [2^-100, 2^101): three integer instructions.  Anything else --
-            // zero, subnormal, tiny, huge, infinite, NaN -- takes the IEEE expansion; the wave skips it when no lane needs it
-            const unsigned ex = (__float_as_uint(a) >> 23) & 0xffu;
-            const bool in_range = (ex - 27u) <= 200u;
+            // |a| in [2^-100, 2^101): two compares on |a| (the sign comes off as an operand modifier).  Anything else -- zero,
+            // subnormal, tiny, huge, infinite, NaN -- takes the IEEE expansion; the wave skips it when no lane needs it
+            const float aa = fabsf(a);
+            const bool in_range = aa >= 0x1.0p-100f && aa < 0x1.0p+101f;
             if (__any(!in_range)) {
                 asm volatile("");       // (a side effect: keeps the compiler from speculating the expansion on every call)
                 const float qi = a / c;
@@ -228,13 +228,22 @@ MI_HD FdF fun_dfun_e(const Model& M, float e1, float e2, float v, float s, float
 // At t = 0 both exponentials are exactly 1 (expf_(+-0) == 1), so the first evaluation needs no exp.
 constexpr float kNever = 100.0f;
 
-template <int MATH, bool UNI = false, bool FILTER = (MI_EDM_FIRE_FILTER != 0)>
+// 0 < vth - I <= 1: the condition under which a negative (or NaN) synaptic variable alone settles will_fire (below).
+// GAP = the host has found it true before the launch (mi_edm.hip launch_evolve): the test is then compile-time true -- as a
+// run-time test inside the state pass it was scalar branches per slice.  (UNI kernels -- uniform divisors in range -- are
+// only launched with it true.)
+template <bool GAP>
+MI_HD bool gap_settles_sign(const Model& M)
+{
+    const float gap = M.vth - M.I;
+    return GAP ? true : (gap > 0.0f && gap <= 1.0f);
+}
+
+template <int MATH, bool UNI = false, bool FILTER = (MI_EDM_FIRE_FILTER != 0), bool GAP = UNI>
 MI_HD bool will_fire(const Model& M, float v0, float s0, float beta)
 {
     const float gap = M.vth - M.I;
-    // UNI kernels are launched only when the host has found 0 < gap <= 1 (and the uniform divisors in range): the tests on
-    // gap below are then compile-time true -- as run-time tests inside the state pass they were scalar branches per slice.
-    const bool gap_ok = UNI ? true : (gap > 0.0f && gap <= 1.0f);
+    const bool gap_ok = gap_settles_sign<GAP>(M);
     // Exact shortcuts: a negative (or NaN) ratio makes log(ratio) NaN, hence pw, thr NaN and `v0 > thr` false.
     // With 0 < gap <= 1 the quotient s0/gap cannot underflow to -0, so s0 < 0 already decides it (no division), and so
     // does a NaN (the poisoned stretch of the lift profile: 3.8 of 16 slices per event at N = 1024); the inhibitory
