@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <new>
+#include <type_traits>
 #include <cstdlib>
 #include <vector>
 
@@ -209,7 +210,7 @@ enum { kTapEvents = 0, kTapMaxEvents, kTapMaxNewton, kTapNewtonCap, kTapEventCap
 // TREE: the block is made of whole warps (N a multiple of 32): arg-min ties as the reference breaks them (tie_key)
 // GAP: the host has checked 0 < vth - I <= 1 (edm::gap_settles_sign; UDIV implies it)
 template <int MATH, bool HETERO, int NS, bool UDIV, bool TAPS = false, bool TREE = true, bool GAP = UDIV>
-__global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, SpikeSeeds sd, unsigned store,
+__global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void evolve_kernel(edm::Model M, SpikeSeeds sd, unsigned store,
                                                               unsigned long long* __restrict__ taps,
                                                               const float* __restrict__ v0,
                                                               const float* __restrict__ s0,
@@ -289,6 +290,9 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
         }
         unsigned crossed = 0;
         float now = 0.0f;
+        // range of |s| over this lane's neurons as the last state pass left it (kTrack; the first pass runs guarded)
+        constexpr bool kTrack = UDIV && !HETERO && MATH == 0;
+        float s_lo = 0.0f, s_hi = INFINITY;
         // Candidate bookkeeping.  Every event needs min over neurons of eventTime().  Neurons that will not
         // fire contribute exactly kNever; the few that will (the bump fronts) need a divergent Newton solve.
         // Instead of running that loop once per 64-neuron slice, each lane records its firing neurons in a
@@ -409,11 +413,16 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
             } else {
                 e1 = edm::expf_<MATH>(-dt);
             }
-            unsigned a = lane;
             const unsigned lane4 = lane * 4u, idx4 = idx * 4u;
             const bool sign_settles = edm::gap_settles_sign<GAP>(M);
             typedef __attribute__((address_space(3))) const float lds_cfloat;
             const unsigned w_base = (unsigned)(uintptr_t)(lds_cfloat*)w_lds;
+            // guard_tag: std::true_type = the exact quotient checks its numerator's range in every slice (edm::div_by), false_type =
+            // the range is known beforehand (below)
+            auto state_pass = [&](auto guard_tag) {
+            constexpr bool kGuard = decltype(guard_tag)::value;
+            float lo = INFINITY, hi = 0.0f;
+            unsigned a = lane;
 #pragma unroll 1                                                            // rolled: measured (DESIGN_HISTORY.md section 4)
             for (unsigned m = store; m != 0u; m &= m - 1u, a += 128u) {      // live slices only
                 const unsigned k = (unsigned)__builtin_ctz(m);
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 asm("v_sad_u32 %0, %1, %2, %3" : "=v"(w_at) : "v"((k << 8) | lane4), "s"(idx4), "v"(w_base));
                 const float wd = *reinterpret_cast<lds_cfloat*>((uintptr_t)w_at);
                 float vv = V[a] * e1;
-                vv = vv + (M.I * (1.0f - e1) + edm::div_by<MATH, UDIV && !HETERO>(so * e1, 1.0f - bk) * (e2 - 1.0f));
+                vv = vv + (M.I * (1.0f - e1) + edm::div_by<MATH, UDIV && !HETERO, kGuard>(so * e1, 1.0f - bk) * (e2 - 1.0f));
                 // reset of the neuron that fired (:615 multiplies every v by (tid != index)): x * 1 == x, so only that
                 // neuron needs the multiply (by 0: NaN stays NaN, a finite value becomes a signed zero) -- and only its
                 // slice looks for it (a scalar branch: idx and k are wave-uniform)
@@ -439,11 +448,29 @@ __global__ __launch_bounds__(kEvolveBlock) void evolve_kernel(edm::Model M, Spik
                 sn = sn + (HETERO ? bk * wd : wd);
                 V[a] = vv;
                 S[a] = sn;
+                if constexpr (kTrack) {          // range of |s| over the lane's neurons (a NaN leaves both bounds alone)
+                    asm("v_min_f32 %0, |%1|, %0" : "+v"(lo) : "v"(sn));
+                    asm("v_max_f32 %0, |%1|, %0" : "+v"(hi) : "v"(sn));
+                }
                 // With 0 < vth - I <= 1 no lane of the slice can fire unless some s is >= 0 (will_fire's first exit): most slices
                 // of most events leave here with one scalar branch -- inside will_fire the same exit costs an exec-mask save /
                 // restore and the two instructions that fold an all-false result into pend.
                 if (!sign_settles || __any(sn >= 0.0f))
                 pend |= (edm::will_fire<MATH, UDIV && !HETERO, (MI_EDM_FIRE_FILTER != 0), GAP>(M, vv, sn, bk) ? 1u : 0u) << pos_of(k);   // (padding lanes: masked below)
+            }
+            s_lo = lo;
+            s_hi = hi;
+            };
+            if constexpr (kTrack) {
+                // The exact quotient (so * e1) / (1 - beta) needs |so * e1| in [2^-100, 2^101) (or a NaN); its own test of that is
+                // two compares and a scalar branch in every slice.  The previous pass left the range of |s| over this lane's
+                // neurons: |so * e1| <= |so| < 2^101, and RN(s_lo * e1) >= 2^-99 puts every |so * e1| above 2^-100 -- then the
+                // whole pass runs without the per-slice test.  (First event, zeros, subnormals, infinities: the guarded pass.)
+                const bool known = s_hi < 0x1.0p+101f && s_lo * e1 >= 0x1.0p-99f;
+                if (__any(!known)) state_pass(std::true_type{});
+                else state_pass(std::false_type{});
+            } else {
+                state_pass(std::true_type{});
             }
             pend &= valid;
             lowest_quiet();

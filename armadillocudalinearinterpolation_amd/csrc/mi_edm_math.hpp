@@ -181,7 +181,9 @@ MI_HD float div_(float a, float b)
 // Checked against `/` bit for bit by tests/test_edm_gpu.py::test_uniform_divisor_quotient_is_the_ieee_quotient.
 // Used where it pays: with eight waves per SIMD (N <= 512, the reference's Driver.cu) Evolve is 13 % faster with it; at
 // N = 1024 (four waves per SIMD) the guard costs what the division saves (profiles/r02_edm_evolve_phases.log).
-template <int MATH, bool UNI>
+// GUARD = false: the caller vouches for |a| in [2^-100, 2^101) or a NaN (evolve_kernel's state pass tracks the range of the
+// synaptic variables it divides), and the quotient is the five operations alone.
+template <int MATH, bool UNI, bool GUARD = true>
 MI_HD float div_by(float a, float c)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -195,6 +197,7 @@ MI_HD float div_by(float a, float c)
             q = fmaf(fmaf(-c, q, a), rc, q);
             // |a| in [2^-100, 2^101): two compares on |a| (the sign comes off as an operand modifier).  Anything else -- zero,
             // subnormal, tiny, huge, infinite, NaN -- takes the IEEE expansion; the wave skips it when no lane needs it
+            if constexpr (!GUARD) return q;
             const float aa = fabsf(a);
             const bool in_range = aa >= 0x1.0p-100f && aa < 0x1.0p+101f;
             if (__any(!in_range)) {

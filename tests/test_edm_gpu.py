@@ -245,6 +245,35 @@ def test_pathological_parameters_terminate_and_match(mi_ctx, kw):
     assert np.array_equal(np.isnan(f), np.isnan(fo)) and np.allclose(f, fo, rtol=0, atol=2e-7, equal_nan=True)
 
 
+@pytest.mark.parametrize("kw", [dict(L=12.0), dict(L=24.0, b1=4.0, b2=3.0), dict(L=12.0, time_horizon=60.0), dict(n_grid=992),
+                                dict(a1=3e38, a2=1e38), dict(a1=1.1e-29, a2=0.7e-29), dict(a1=7.0, a2=7.0, b1=3.5, b2=3.5)])
+def test_quotient_range_tracking_of_the_state_pass(mi_ctx, evolve_form, kw):
+    """The throughput kernel of a launch that fills the device (R >= 12 per CU) divides by 1 - beta with a five-operation
+    exact quotient that is valid for numerators in [2^-100, 2^101); instead of testing that in every slice, the state
+    pass tracks the range of |s| per lane and takes an unguarded pass when the range allows it (csrc/mi_edm.hip).
+    Cases in which the two passes alternate: rings on which the activity dies after 50-100 events and the last event is a
+    "no neuron fires" step of 100 time units (exp(-100) pushes every numerator below 2^-100: guarded pass, IEEE expansion),
+    a grid with padding lanes, couplings that overflow to infinity, sit below 2^-100 altogether, or vanish exactly.
+    Every tap must be the oracle's bits."""
+    if evolve_form == "workgroup_per_realisation":
+        pytest.skip("the latency form has no such pass")
+    import armadillocudalinearinterpolation_amd as mi
+    R = 3500
+    kw = dict(dict(n_grid=1024, max_events=800), **kw)
+    edm = mi.EventDrivenMap(mi_ctx, [13.0589], R, **kw)
+    edm.ComputeF(Z_DRIVER)
+    dbg = edm.debug_read()
+    # beta_stddev = 0: the R realisations are R copies of one computation -- the oracle evolves that one
+    _, d = oracle.edm_compute_f(oracle.edm_default_params(n_real=1, **kw), Z_DRIVER)
+    for k in ("w", "v", "s"):
+        assert np.array_equal(dbg[k], d[k], equal_nan=True), (kw, k)
+    S = edm.params.n_spikes
+    for k in ("t0", "i0", "t1", "i1"):
+        assert np.array_equal(np.asarray(dbg[k]).reshape(S, R), np.repeat(np.asarray(d[k]).reshape(S, 1), R, axis=1), equal_nan=True), (kw, k)
+    assert np.array_equal(np.asarray(dbg["accept"]), np.repeat(np.asarray(d["accept"]), R))
+    edm.close()
+
+
 def test_setters_and_second_call(mi_ctx):
     """SetNoThreads(512) then ComputeF (Driver.cu:69-71) and a perturbed Z (finite-difference column)."""
     import armadillocudalinearinterpolation_amd as mi
