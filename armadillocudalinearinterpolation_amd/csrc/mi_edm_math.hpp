@@ -261,9 +261,10 @@ MI_HD bool will_fire(const Model& M, float v0, float s0, float beta)
     // is the exact path's whenever the two evaluations could disagree.  Error budget: the two values of
     // pw = ratio^(1/beta) differ relatively by at most ln 2 |log2(ratio)/beta| 2^-22 (argument error of either
     // exponential) + a few ulp, i.e. < 3.5e-6 under the guard |log2(ratio)/beta| <= 16; thr is affine in pw and ratio
-    // with coefficients bounded by the magnitudes summed in `mag`, so |thr_hw - thr_exact| < 4e-6 mag: a factor 25
-    // inside the margin.  tests/test_edm_gpu.py compares the decisions of both forms on dense samples around the
-    // threshold (math probe ops 6, 7) and every stage tap of ComputeF with the oracle.
+    // with coefficients bounded by the magnitudes summed in `mag` = |vth| pw + |I| (1 + pw) + |c| (ratio + pw), so
+    // |thr_hw - thr_exact| < 4e-6 mag: a factor 25 inside the margin 1e-4 mag (the code uses a bound of mag that is cheaper
+    // to form).  tests/test_edm_gpu.py compares the decisions of both forms on dense samples around the threshold (math
+    // probe ops 6, 7) and every stage tap of ComputeF with the oracle.
     // Written without branches (one `decided` flag per lane): as nested ifs the pre-decision was five scalar branches per
     // slice, and the event loop is bound by those as much as by its vector instructions (profiles/r04_edm_evolve_steps.log).
     if constexpr (MATH == 0 && FILTER) {
@@ -272,10 +273,12 @@ MI_HD bool will_fire(const Model& M, float v0, float s0, float beta)
             const float ex = __builtin_amdgcn_logf(rf) * __builtin_amdgcn_rcpf(beta);       // log2(ratio) / beta
             const float pwf = __builtin_amdgcn_exp2f(ex);
             const float c = gap * __builtin_amdgcn_rcpf(beta - 1.0f);
-            const float thrf = (M.vth * pwf + M.I * (1.0f - pwf)) - c * (rf - pwf);
-            const float mag = (fabsf(M.vth) * pwf + fabsf(M.I) * (1.0f + pwf)) + fabsf(c) * (rf + pwf);
-            const float margin = 1.0e-4f * mag;
-            const bool usable = (rf >= 0x1.0p-40f) & (rf <= 0x1.0p+40f) & (fabsf(ex) <= 16.0f) & (mag < INFINITY);   // false for NaN anywhere
+            // thr = vth pw + I (1 - pw) - c (ratio - pw) = I + gap pw - c (ratio - pw): two fused multiply-adds (this is the
+            // approximate side: any form within the margin will do), and a margin from the slightly coarser bound
+            // mag <= (|vth| + |I|) (1 + pw) + |c| (ratio + pw) whose coefficients are the same for every neuron of the launch
+            const float thrf = fmaf(-c, rf - pwf, fmaf(gap, pwf, M.I));
+            const float margin = fmaf(1.0e-4f * fabsf(c), rf + pwf, (1.0e-4f * (fabsf(M.vth) + fabsf(M.I))) * (1.0f + pwf));
+            const bool usable = (rf >= 0x1.0p-40f) & (rf <= 0x1.0p+40f) & (fabsf(ex) <= 16.0f) & (margin < INFINITY);   // false for NaN anywhere
             const bool above = v0 > thrf + margin, below = v0 < thrf - margin;
             if (usable & (above | below)) return above;
         }
