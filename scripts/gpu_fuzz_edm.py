@@ -1,6 +1,7 @@
 """Differential fuzz of the EventDrivenMap pipeline (EXACT math) against oracle/edm_oracle.c (run on the GPU box;
-not part of the test suite).  Random model parameters, grid sizes, spike counts, heterogeneity and both evolve
-kernel forms; every stage tap must be bit-identical."""
+not part of the test suite).  Random model parameters, grid sizes, spike counts, heterogeneity, both evolve kernel
+forms and, in three cases of ten, a launch large enough for the throughput kernel's device-filling variant; every stage
+tap must be bit-identical."""
 import os
 import sys
 import time
@@ -15,7 +16,7 @@ def run(budget, seed, ctx=None):
     import armadillocudalinearinterpolation_amd as mi
     rng = np.random.default_rng(seed)
     ctx = ctx or mi.Context(0)
-    t0, cases, accepted = time.time(), 0, 0
+    t0, cases, accepted, filled = time.time(), 0, 0, 0
     beat = t0
     while time.time() - t0 < budget:
         if time.time() - beat > 60.0:          # a sign of life every minute (a silent GPU command is taken to be hung)
@@ -31,6 +32,32 @@ def run(budget, seed, ctx=None):
         )
         c = rng.uniform(0.2, 0.5)
         Z = np.concatenate([[c], np.sort(rng.uniform(0.3, 2.5, S - 1))]) if S > 1 else np.array([c])
+        if rng.random() < 0.3:
+            # A launch that fills the device (the throughput kernel with the exact uniform-divisor quotient, its range tracking
+            # and the host-checked gap flag only runs from 12 realisations per CU): 3200 identical realisations against ONE
+            # oracle realisation.  Some with a threshold gap outside (0, 1] and some with a far field that decays to tiny values.
+            kw.update(n_real=3200, beta_stddev=0.0, n_grid=int(rng.choice([64, 256, 512, 992, 1000, 1024])), max_events=1500)
+            if rng.random() < 0.25:
+                kw["I"] = float(np.float32(rng.uniform(0.5, 1.3)))
+            if rng.random() < 0.25:
+                kw["b1"], kw["b2"] = float(np.float32(4.0 * kw["b1"])), float(np.float32(4.0 * kw["b2"]))
+            os.environ["MI_EDM_WAVES_PER_REALISATION"] = "1"
+            R = kw.pop("n_real")
+            edm = mi.EventDrivenMap(ctx, [kw.pop("beta_mean")], R, **kw)
+            edm.ComputeF(Z)
+            dbg = edm.debug_read()
+            _, d = oracle.edm_compute_f(oracle.edm_default_params(beta_mean=edm.params.beta_mean, n_real=1, **kw), Z)
+            bad = [k for k in ("seed_ind", "w", "v", "s") if not np.array_equal(dbg[k], d[k], equal_nan=True)]
+            bad += [k for k in ("t0", "i0", "t1", "i1")
+                    if not np.array_equal(np.asarray(dbg[k]).reshape(S, R), np.repeat(np.asarray(d[k]).reshape(S, 1), R, axis=1), equal_nan=True)]
+            if bad or not np.array_equal(np.asarray(dbg["accept"]), np.repeat(np.asarray(d["accept"]), R)):
+                print("MISMATCH (filled device)", bad, kw, Z, flush=True)
+                raise AssertionError("differential fuzz mismatch (details printed above)")
+            accepted += int(d["accept"][0])
+            cases += 1
+            filled += 1
+            edm.close()
+            continue
         os.environ["MI_EDM_WAVES_PER_REALISATION"] = str(rng.choice([1, 4]))
         edm = mi.EventDrivenMap(ctx, [kw.pop("beta_mean")], kw.pop("n_real"), **kw)
         f, partial = edm.ComputeF(Z, want_partial=True)
@@ -45,8 +72,9 @@ def run(budget, seed, ctx=None):
         cases += 1
         edm.close()
     os.environ.pop("MI_EDM_WAVES_PER_REALISATION", None)
-    print("edm fuzz ok: %d cases in %.0f s (%d with accepted realisations)" % (cases, time.time() - t0, accepted), flush=True)
-    return {"cases": cases, "accepted": accepted}
+    print("edm fuzz ok: %d cases in %.0f s (%d with accepted realisations, %d of them device-filling launches)"
+          % (cases, time.time() - t0, accepted, filled), flush=True)
+    return {"cases": cases, "accepted": accepted, "filled": filled}
 
 
 def main():
