@@ -941,7 +941,6 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
     mi_ctx* ctx = e->ctx;
     const unsigned N = e->p.n_grid, R = e->p.n_real;
     const bool hetero = e->p.beta_stddev != 0.0f;
-    const unsigned cus = (unsigned)(ctx->compute_units > 0 ? ctx->compute_units : 256);
     const size_t lds_bytes = evolve_lds_bytes(hetero, live);
     // One workgroup per four realisations, however many that is: the hardware's workgroup dispatcher then IS the work
     // queue (a finished workgroup's slot goes to the next four realisations; per-workgroup set-up is the 4 KiB coupling
@@ -986,15 +985,15 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
         if (gap_ok) MI_EVOLVE_G(H, NS, UD, true);                                                                 \
         else MI_EVOLVE_G(H, NS, false, false);                                                                    \
     } while (0)
-        // The exact quotient by uniform divisors (edm::div_by) pays once the launch brings three or more waves per SIMD
-        // (N = 512: R = 16384 10.25 -> 9.00 ms, R = 4000 3.10 -> 2.91 ms, but R = 1000 -- one wave per SIMD -- 1.59 -> 2.10 ms).
-        // Round 4: with its guard down to three integer instructions it also pays at N = 1024 (137.7 -> 134.2 ms at R = 125 000).
-        // (edm::div_by<.., true> relies on its divisors -- 1 - beta, beta - 1 and vth - I -- lying in [2^-20, 2^20] in magnitude)
+        // The exact quotient by uniform divisors (edm::div_by): at every realisation count since the state pass runs it without
+        // its guard (range tracking) -- R = 600 .. 3000: -4 .. -10 %, beyond: the kernel it always took (gpurun_out/r04_ab20.log).
+        // (Rounds 2-3 took it only from three waves per SIMD: with its guard it was slower on an underfilled device.)
+        // edm::div_by<.., true> relies on its divisors -- 1 - beta, beta - 1 and vth - I -- lying in [2^-20, 2^20] in magnitude.
         auto in_range = [](float c) { return fabsf(c) >= 0x1.0p-20f && fabsf(c) <= 0x1.0p+20f; };
         const float gap = e->p.vth - e->p.I;               // 0 < vth - I <= 1 (edm::gap_settles_sign): a template flag of the kernels
         const bool gap_ok = gap > 0.0f && gap <= 1.0f;
         const bool uniform_divisors_ok = in_range(1.0f - e->p.beta_mean) && in_range(e->p.beta_mean - 1.0f) && in_range(gap) && gap_ok;
-        const bool udiv = MATH == 0 && !hetero && Reff >= cus * 12u && !e->no_uniform_div && uniform_divisors_ok;
+        const bool udiv = MATH == 0 && !hetero && !e->no_uniform_div && uniform_divisors_ok;
         if (hetero) { if (three) MI_EVOLVE(true, 3, false); else MI_EVOLVE(true, kMaxSpikes, false); }
         else if (udiv) { if (three) MI_EVOLVE(false, 3, true); else MI_EVOLVE(false, kMaxSpikes, true); }
         else { if (three) MI_EVOLVE(false, 3, false); else MI_EVOLVE(false, kMaxSpikes, false); }
