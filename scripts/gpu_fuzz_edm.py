@@ -1,6 +1,6 @@
 """Differential fuzz of the EventDrivenMap pipeline (EXACT math) against oracle/edm_oracle.c (run on the GPU box;
 not part of the test suite).  Random model parameters, grid sizes, spike counts, heterogeneity, both evolve kernel
-forms and, in three cases of ten, a launch large enough for the throughput kernel's device-filling variant; every stage
+forms and, in three cases of ten, a launch of more realisations than the device holds at once; every stage
 tap must be bit-identical."""
 import os
 import sys
@@ -33,8 +33,8 @@ def run(budget, seed, ctx=None):
         c = rng.uniform(0.2, 0.5)
         Z = np.concatenate([[c], np.sort(rng.uniform(0.3, 2.5, S - 1))]) if S > 1 else np.array([c])
         if rng.random() < 0.3:
-            # A launch that fills the device (the throughput kernel with the exact uniform-divisor quotient, its range tracking
-            # and the host-checked gap flag only runs from 12 realisations per CU): 3200 identical realisations against ONE
+            # A launch of more realisations than the device holds at once (workgroups in several rounds, the automatic kernel
+            # choice lands on the throughput form with the exact uniform-divisor quotient): 3200 identical realisations against ONE
             # oracle realisation.  Some with a threshold gap outside (0, 1] and some with a far field that decays to tiny values.
             kw.update(n_real=3200, beta_stddev=0.0, n_grid=int(rng.choice([64, 256, 512, 992, 1000, 1024])), max_events=1500)
             if rng.random() < 0.25:

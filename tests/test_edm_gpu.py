@@ -248,7 +248,7 @@ def test_pathological_parameters_terminate_and_match(mi_ctx, kw):
 @pytest.mark.parametrize("kw", [dict(L=12.0), dict(L=24.0, b1=4.0, b2=3.0), dict(L=12.0, time_horizon=60.0), dict(n_grid=992),
                                 dict(a1=3e38, a2=1e38), dict(a1=1.1e-29, a2=0.7e-29), dict(a1=7.0, a2=7.0, b1=3.5, b2=3.5)])
 def test_quotient_range_tracking_of_the_state_pass(mi_ctx, evolve_form, kw):
-    """The throughput kernel of a launch that fills the device (R >= 12 per CU) divides by 1 - beta with a five-operation
+    """The throughput kernel (one wave per realisation, homogeneous beta, EXACT math) divides by 1 - beta with a five-operation
     exact quotient that is valid for numerators in [2^-100, 2^101); instead of testing that in every slice, the state
     pass tracks the range of |s| per lane and takes an unguarded pass when the range allows it (csrc/mi_edm.hip).
     Cases in which the two passes alternate: rings on which the activity dies after 50-100 events and the last event is a
