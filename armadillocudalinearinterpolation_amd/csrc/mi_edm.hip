@@ -209,7 +209,8 @@ __device__ __forceinline__ void wave_argmin(float& best, unsigned& key)
 enum { kTapEvents = 0, kTapMaxEvents, kTapMaxNewton, kTapNewtonCap, kTapEventCap, kTapAccepted, kTapNoFiring, kTapTies, kTapCount };
 // TREE: the block is made of whole warps (N a multiple of 32): arg-min ties as the reference breaks them (tie_key)
 // GAP: the host has checked 0 < vth - I <= 1 (edm::gap_settles_sign; UDIV implies it)
-template <int MATH, bool HETERO, int NS, bool UDIV, bool TAPS = false, bool TREE = true, bool GAP = UDIV>
+// ONE: the host has proved that ONE correction step makes the quotient by 1 - beta exact (divisor_check_kernel; UDIV only)
+template <int MATH, bool HETERO, int NS, bool UDIV, bool TAPS = false, bool TREE = true, bool GAP = UDIV, bool ONE = false>
 __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void evolve_kernel(edm::Model M, SpikeSeeds sd, unsigned store,
                                                               unsigned long long* __restrict__ taps,
                                                               const float* __restrict__ v0,
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(8,
                         const unsigned a = sl * 128u + (i & 63u);
                         const float bk = HETERO ? B[sl * 64u + (i & 63u)] : M.beta_mean;
                         uint32_t it = 0;
-                        const float tau = edm::newton_time_paired<MATH, UDIV && !HETERO>(M, V[a], S[a], bk, lane >= 32u, TAPS ? &it : nullptr);
+                        const float tau = edm::newton_time_paired<MATH, UDIV && !HETERO, ONE>(M, V[a], S[a], bk, lane >= 32u, TAPS ? &it : nullptr);
                         if (lane < 32u) {
                             if constexpr (TAPS) {
                                 tap_newton = max(tap_newton, it);
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(8,
                 asm("v_sad_u32 %0, %1, %2, %3" : "=v"(w_at) : "v"((k << 8) | lane4), "s"(idx4), "v"(w_base));
                 const float wd = *reinterpret_cast<lds_cfloat*>((uintptr_t)w_at);
                 float vv = V[a] * e1;
-                vv = vv + (M.I * (1.0f - e1) + edm::div_by<MATH, UDIV && !HETERO, kGuard>(so * e1, 1.0f - bk) * (e2 - 1.0f));
+                vv = vv + (M.I * (1.0f - e1) + edm::div_by<MATH, UDIV && !HETERO, kGuard, ONE>(so * e1, 1.0f - bk) * (e2 - 1.0f));
                 // reset of the neuron that fired (:615 multiplies every v by (tid != index)): x * 1 == x, so only that
                 // neuron needs the multiply (by 0: NaN stays NaN, a finite value becomes a signed zero) -- and only its
                 // slice looks for it (a scalar branch: idx and k are wave-uniform)
@@ -748,6 +749,18 @@ __global__ __launch_bounds__(256) void replicate_events_kernel(unsigned S, unsig
     }
 }
 
+// Does ONE correction step give the IEEE quotient a / c for every a?  All 2^23 significands of a in [1, 2): inside the range
+// edm::div_by guards, the quotient scales exactly with a's exponent, and both forms are odd in a and in c.  bad[0] counts
+// the significands for which the two differ (none, for every divisor seen so far; the launch does not rely on that).
+__global__ __launch_bounds__(256) void divisor_check_kernel(float c, unsigned* __restrict__ bad)
+{
+    const unsigned m = blockIdx.x * 256u + threadIdx.x;              // grid = 2^23 / 256 workgroups
+    const float a = __uint_as_float(0x3f800000u | m);
+    const bool differs = edm::div_by<0, true, false, true>(a, c) != a / c;
+    const unsigned long long d = __ballot(differs);
+    if (d != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(bad, (unsigned)__builtin_popcountll(d));
+}
+
 template <int MATH>
 __global__ void math_probe_kernel(int op, const float* a, const float* b, float* out, size_t n)
 {
@@ -773,6 +786,10 @@ __global__ void math_probe_kernel(int op, const float* a, const float* b, float*
             break;
         }
         case 12: r = edm::other_half(a[i], (threadIdx.x & 32u) != 0u); break;   // a[i ^ 32]: the lane-pair exchange of the paired solves
+        case 13:                                                  // op 4 with ONE correction step (only exact for divisors that
+            r = (fabsf(b[0]) >= 0x1.0p-20f && fabsf(b[0]) <= 0x1.0p+20f)   // pass mi_edm_divisor_check; the caller decides)
+                    ? edm::div_by<MATH, true, true, true>(a[i], b[0]) : a[i] / b[0];
+            break;
         default: r = edm::erfinvf_<MATH>(a[i]); break;
     }
     out[i] = r;
@@ -808,6 +825,9 @@ struct mi_edm {
     // test / tuning knobs (mi_edm_set_kernel_choice); every choice gives bit-identical results
     int waves_per_real = 0;            // 1 | 4 forces an evolve kernel form (0: by realisation count)
     bool no_uniform_div = false;       // never take the exact quotient by wave-uniform divisors
+    // one-step quotient (edm::div_by ONE): the divisor 1 - beta it was last proved (or refuted) for; NaN = none yet
+    float checked_divisor = NAN;
+    bool one_step_exact = false;
 };
 
 namespace {
@@ -934,6 +954,24 @@ int evolve_form(const mi_edm* e)
     return e->waves_per_real ? e->waves_per_real : ((Reff < kWgNarrow) ? 4 : 1);
 }
 
+// Is the ONE-step quotient by c exact (edm::div_by ONE)?  Proved or refuted on the device over every significand, once per
+// divisor value (about 10 us of kernel + a 4-byte read-back; the result is kept with the handle).
+mi_status one_step_quotient_exact(mi_edm* e, float c, bool* exact)
+{
+    mi_ctx* ctx = e->ctx;
+    if (!(e->checked_divisor == c)) {        // (NaN: nothing checked yet)
+        MI_HIP(ctx, hipMemsetAsync(e->d_aux + 1, 0, sizeof(unsigned), ctx->stream));
+        hipLaunchKernelGGL(divisor_check_kernel, dim3((1u << 23) / 256u), dim3(256), 0, ctx->stream, c, e->d_aux + 1);
+        MI_LAUNCH_CHECK(ctx, "divisor check kernel");
+        MI_HIP(ctx, hipMemcpyAsync(e->h_aux + 1, e->d_aux + 1, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        MI_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        e->one_step_exact = e->h_aux[1] == 0u;
+        e->checked_divisor = c;
+    }
+    *exact = e->one_step_exact;
+    return MI_OK;
+}
+
 // live: the lift kernel's live-slice mask (wave-per-realisation form only; ignored by the latency form)
 template <int MATH>
 mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
@@ -970,20 +1008,21 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
     if (wpr == 1) {
     // (N not a multiple of 32 -- no launch the reference could make -- runs the !TREE instantiation: ties to the lowest index)
     const bool whole_warps = (N & 31u) == 0u;
-#define MI_EVOLVE_G(H, NS, UD, G)                                                                                 \
+#define MI_EVOLVE_G(H, NS, UD, G, O)                                                                              \
     do {                                                                                                          \
         if (whole_warps)                                                                                          \
-            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, UD, false, true, G>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
+            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, UD, false, true, G, O>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
                                M, sd, live, nullptr, e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept);             \
         else                                                                                                      \
-            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, false, false, false, G>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
+            hipLaunchKernelGGL((evolve_kernel<MATH, H, NS, false, false, false, G, false>), dim3(blocks), dim3(kEvolveBlock), lds_bytes, ctx->stream, \
                                M, sd, live, nullptr, e->d_v, e->d_s, e->d_w, t0, i0, t1, i1, accept);             \
     } while (0)
-    // (UD is only ever true together with gap_ok)
+    // (UD is only ever true together with gap_ok, and the one-step quotient only with UD)
 #define MI_EVOLVE(H, NS, UD)                                                                                      \
     do {                                                                                                          \
-        if (gap_ok) MI_EVOLVE_G(H, NS, UD, true);                                                                 \
-        else MI_EVOLVE_G(H, NS, false, false);                                                                    \
+        if (!gap_ok) MI_EVOLVE_G(H, NS, false, false, false);                                                     \
+        else if (UD && one_step) MI_EVOLVE_G(H, NS, UD, true, UD);                                                \
+        else MI_EVOLVE_G(H, NS, UD, true, false);                                                                 \
     } while (0)
         // The exact quotient by uniform divisors (edm::div_by): at every realisation count since the state pass runs it without
         // its guard (range tracking) -- R = 600 .. 3000: -4 .. -10 %, beyond: the kernel it always took (gpurun_out/r04_ab20.log).
@@ -994,6 +1033,11 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
         const bool gap_ok = gap > 0.0f && gap <= 1.0f;
         const bool uniform_divisors_ok = in_range(1.0f - e->p.beta_mean) && in_range(e->p.beta_mean - 1.0f) && in_range(gap) && gap_ok;
         const bool udiv = MATH == 0 && !hetero && !e->no_uniform_div && uniform_divisors_ok;
+        bool one_step = false;                             // a single correction step of that quotient, when it is exact for 1 - beta
+        if (udiv && whole_warps) {
+            const mi_status st = one_step_quotient_exact(e, 1.0f - e->p.beta_mean, &one_step);
+            if (st != MI_OK) return st;
+        }
         if (hetero) { if (three) MI_EVOLVE(true, 3, false); else MI_EVOLVE(true, kMaxSpikes, false); }
         else if (udiv) { if (three) MI_EVOLVE(false, 3, true); else MI_EVOLVE(false, kMaxSpikes, true); }
         else { if (three) MI_EVOLVE(false, 3, false); else MI_EVOLVE(false, kMaxSpikes, false); }
@@ -1109,7 +1153,7 @@ mi_status mi_edm_create(mi_ctx* ctx, const mi_edm_params* p, mi_edm** out)
     if (err == hipSuccess) err = hipMalloc(&e->d_one, kOneBytes);
     if (err == hipSuccess) err = hipMalloc(&e->d_aux, 2 * sizeof(unsigned));
     if (err == hipSuccess) err = hipHostMalloc(&e->h_result, kResultBytes);
-    if (err == hipSuccess) err = hipHostMalloc(&e->h_aux, sizeof(unsigned));
+    if (err == hipSuccess) err = hipHostMalloc(&e->h_aux, 2 * sizeof(unsigned));
     for (int i = 0; i < 4 && err == hipSuccess; ++i) err = hipEventCreate(&e->ev[i]);
     if (err != hipSuccess) {
         mi_edm_destroy(e);

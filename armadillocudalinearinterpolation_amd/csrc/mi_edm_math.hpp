@@ -183,7 +183,12 @@ MI_HD float div_(float a, float b)
 // N = 1024 (four waves per SIMD) the guard costs what the division saves (profiles/r02_edm_evolve_phases.log).
 // GUARD = false: the caller vouches for |a| in [2^-100, 2^101) or a NaN (evolve_kernel's state pass tracks the range of the
 // synaptic variables it divides), and the quotient is the five operations alone.
-template <int MATH, bool UNI, bool GUARD = true>
+// ONE = true: a single correction step.  With rc = RN(1 / c) the first corrected quotient is already RN(a / c) for every
+// divisor tried (and the second step then changes nothing); rather than lean on that, the host PROVES it for the launch's
+// divisor before it picks a ONE kernel: divisor_check_kernel (mi_edm.hip) compares the one-step quotient with the IEEE
+// quotient for all 2^23 significands of a (the quotient scales exactly with a's exponent inside the guarded range and is
+// sign-symmetric), once per divisor value.
+template <int MATH, bool UNI, bool GUARD = true, bool ONE = false>
 MI_HD float div_by(float a, float c)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -194,7 +199,7 @@ MI_HD float div_by(float a, float c)
             const float rc = 1.0f / c;
             const float q0 = a * rc;
             float q = fmaf(fmaf(-c, q0, a), rc, q0);
-            q = fmaf(fmaf(-c, q, a), rc, q);
+            if constexpr (!ONE) q = fmaf(fmaf(-c, q, a), rc, q);
             // |a| in [2^-100, 2^101): two compares on |a| (the sign comes off as an operand modifier).  Anything else -- zero,
             // subnormal, tiny, huge, infinite, NaN -- takes the IEEE expansion; the wave skips it when no lane needs it
             if constexpr (!GUARD) return q;
@@ -213,13 +218,13 @@ MI_HD float div_by(float a, float c)
 }
 
 // fun/dfun, EventDrivenMap.cu:544-552, sharing e1 = exp(-t), e2 = exp((1-beta) t)
-template <int MATH, bool UNI = false>
+template <int MATH, bool UNI = false, bool ONE = false>
 MI_HD FdF fun_dfun_e(const Model& M, float e1, float e2, float v, float s, float beta)
 {
     const float se = s * e1;
     FdF r;
-    r.f = ((v * e1 + M.I * (1.0f - e1)) + div_by<MATH, UNI>(se, 1.0f - beta) * (e2 - 1.0f)) - M.vth;
-    r.df = ((M.I * e1 - v * e1) + se * e2) + div_by<MATH, UNI>(se * (e2 - 1.0f), beta - 1.0f);
+    r.f = ((v * e1 + M.I * (1.0f - e1)) + div_by<MATH, UNI, true, ONE>(se, 1.0f - beta) * (e2 - 1.0f)) - M.vth;
+    r.df = ((M.I * e1 - v * e1) + se * e2) + div_by<MATH, UNI, true, ONE>(se * (e2 - 1.0f), beta - 1.0f);
     return r;
 }
 
@@ -344,13 +349,13 @@ __device__ __forceinline__ float other_half(float x, bool upper)
 // the same operands, so t is the same bit pattern in both lanes and equal to newton_time's: -t is (-1) t; the
 // derivative's quotient a / (beta - 1) is formed as -(a / (1 - beta)), the same number (beta - 1 = -(1 - beta) exactly,
 // and IEEE division is sign-symmetric; only the sign of a NaN can differ, and a NaN time never wins the arg-min).
-template <int MATH, bool UNI = false>
+template <int MATH, bool UNI = false, bool ONE = false>
 __device__ __forceinline__ float newton_time_paired(const Model& M, float v0, float s0, float beta, bool upper,
                                                     uint32_t* iters = nullptr)
 {
     const float omb = 1.0f - beta;
     float t = 0.0f;
-    FdF r = fun_dfun_e<MATH, UNI>(M, 1.0f, 1.0f, v0, s0, beta);
+    FdF r = fun_dfun_e<MATH, UNI, ONE>(M, 1.0f, 1.0f, v0, s0, beta);
     float f = r.f, df = r.df;
     const float cx = upper ? omb : -1.0f;
     uint32_t counter = 0;
@@ -361,7 +366,7 @@ __device__ __forceinline__ float newton_time_paired(const Model& M, float v0, fl
         pair_values(e, e1, e2);                           // both lanes now hold both exponentials
         const float se = s0 * e1;
         const float em1 = e2 - 1.0f;
-        float q = div_by<MATH, UNI>(upper ? se * em1 : se, omb);
+        float q = div_by<MATH, UNI, true, ONE>(upper ? se * em1 : se, omb);
         q = upper ? -q : q;
         const float ve = v0 * e1;
         const float fv = ((ve + M.I * (1.0f - e1)) + q * em1) - M.vth;     // :546 (meaningful in the lower lane)

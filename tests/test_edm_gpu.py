@@ -69,6 +69,31 @@ def test_uniform_divisor_quotient_is_the_ieee_quotient(mi_ctx, evolve_form):
         assert ok.all(), ("device IEEE division differs from numpy", c)
 
 
+def test_one_correction_step_of_the_uniform_divisor_quotient(mi_ctx, evolve_form):
+    """With rc = RN(1 / c), q0 = RN(a rc) and ONE step q1 = RN(q0 + RN(a - c q0) rc), q1 is the IEEE quotient for every
+    numerator: all 2^23 significands at four exponents (the quotient scales exactly with the numerator's exponent inside
+    the guarded range [2^-100, 2^101)), both signs, for the reference's divisors, awkward ones (significand all ones, one
+    ulp above a power of two) and 40 random ones.  The launch does not rely on this observation -- it proves it for its
+    own divisor on the device before it picks a one-step kernel (divisor_check_kernel, csrc/mi_edm.hip) -- but the
+    product only gets faster where the check passes, and this is the evidence that it does."""
+    if evolve_form != "auto":
+        pytest.skip("no evolve kernel involved")
+    rng = np.random.default_rng(23)
+    mant = np.arange(1 << 23, dtype=np.uint32)
+    a = np.concatenate([((np.uint32(s) << 31) | (np.uint32(e) << 23) | mant).view(np.float32)
+                        for s, e in ((0, 127), (1, 127), (0, 27), (1, 227), (0, 200))])
+    beta = np.float32(13.0589)
+    divisors = [np.float32(1.0) - beta, beta - np.float32(1.0), np.float32(1.0) - np.float32(0.9), np.float32(3.0), np.float32(-7.0),
+                np.float32(1.9999999), np.float32(0.99999994), np.float32(1.0000001), np.float32(2.0 ** -20), np.float32(2.0 ** 20)]
+    divisors += list((rng.uniform(1.0, 2.0, 40) * 2.0 ** rng.integers(-6, 7, 40) * rng.choice([-1.0, 1.0], 40)).astype(np.float32))
+    for c in divisors:
+        cb = np.concatenate([np.full(4, c, np.float32), a[4:]])
+        got = _probe(mi_ctx, 0, 13, a, cb)
+        want = _probe(mi_ctx, 0, 5, a, cb)
+        same = got.view(np.uint32) == want.view(np.uint32)
+        assert same.all(), (c, a[~same][:5], got[~same][:5], want[~same][:5])
+
+
 def test_firing_test_pre_decision_never_changes_the_decision(mi_ctx, evolve_form):
     """will_fire (csrc/mi_edm_math.hpp) settles cases that are clear of the threshold with the hardware transcendentals and
     leaves the rest to the exact path: both forms must give the same decision everywhere -- checked on synaptic values over
