@@ -262,7 +262,9 @@ mi_status mi_edm_set_params(mi_edm* e, const mi_edm_params* p);
 /* Tuning / test knob; every choice gives bit-identical results (tests/test_edm_gpu.py runs each case under all of them).
  * waves_per_realisation: 0 = by realisation count (default: a workgroup of four waves per realisation below 600
  * realisations, one wave per realisation from there), 1 or 4 = that form always.  uniform_division: 1 (default) = the
- * five-operation exact quotient where a divisor is the same for the whole launch, 0 = IEEE division everywhere. */
+ * exact quotient in three or five operations (multiply by the divisor's rounded reciprocal + one or two correction steps;
+ * one only where the device has proved it exact for that divisor) where a divisor is the same for the whole launch,
+ * 0 = IEEE division everywhere. */
 mi_status mi_edm_set_kernel_choice(mi_edm* e, int waves_per_realisation, int uniform_division);
 /* ComputeF (EventDrivenMap.cu:154-240).  z: host, n_spikes doubles (c, Z1..);
  * f: host, n_spikes doubles.  partial (optional, may be NULL): host,
