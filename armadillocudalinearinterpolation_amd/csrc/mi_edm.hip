@@ -833,11 +833,12 @@ struct mi_edm {
 namespace {
 
 constexpr size_t kResultBytes = 8 * 4 + 8 + (2 * 8 + 1) * 8;   // mean f32[8] | count u32 (+pad) | partial block f64[2*8+1]
-// evolve kernel choice by realisation count (launch_evolve): below kWgNarrow four waves per realisation (latency
-// form), else one wave per realisation (throughput form).  scripts/gpu_edm_wpr.py, N = 1024: R <= 256 4.6 -> 2.6 ms,
-// R = 1000 equal, R >= 2000 the throughput form wins (2x at 16 K); 16 waves per realisation were slower than 4
-// everywhere (3.1 ms): the event's critical path is the Newton solve and the exp chain, not the state pass.
-constexpr unsigned kWgNarrow = 600;
+// evolve kernel choice by realisation count (launch_evolve): four waves per realisation (latency form) while every
+// realisation can have a CU of its own and there are enough of them, else one wave per realisation (throughput form).
+// scripts/gpu_edm_wpr.py on the round-4 kernels (profiles/r04_edm_waves_per_realisation.log), four waves against one:
+// N = 1024: R = 64 .. 256 2.35 vs 2.80 ms, R = 8 .. 32 3.05 vs 2.79 ms, R = 300 .. 512 equal, R = 600 3.24 vs 2.83 ms;
+// N = 512: R = 64 .. 256 1.10 vs 1.19 ms, otherwise the throughput form.  Two or sixteen waves per realisation never won.
+constexpr unsigned kWgLow = 48;
 // t0 f32[8] | t1 f32[8] | i0 u16[8] | i1 u16[8] | accept u32
 constexpr size_t kOneT0 = 0, kOneT1 = 32, kOneI0 = 64, kOneI1 = 80, kOneAccept = 96, kOneBytes = 128;
 
@@ -951,7 +952,9 @@ int evolve_form(const mi_edm* e)
     const bool hetero = e->p.beta_stddev != 0.0f;
     const bool dedup = e->p.dedup_identical != 0 && !hetero && e->p.n_real > 1;
     const unsigned Reff = dedup ? 1u : e->p.n_real;
-    return e->waves_per_real ? e->waves_per_real : ((Reff < kWgNarrow) ? 4 : 1);
+    if (e->waves_per_real) return e->waves_per_real;
+    const unsigned cus = (unsigned)(e->ctx->compute_units > 0 ? e->ctx->compute_units : 256);
+    return (Reff >= kWgLow && Reff <= cus) ? 4 : 1;
 }
 
 // Is the ONE-step quotient by c exact (edm::div_by ONE)?  Proved or refuted on the device over every significand, once per

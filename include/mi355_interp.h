@@ -260,8 +260,8 @@ mi_status mi_edm_destroy(mi_edm* e);
 /* setters of EventDrivenMap.hpp:27-51 arrive as a new parameter block */
 mi_status mi_edm_set_params(mi_edm* e, const mi_edm_params* p);
 /* Tuning / test knob; every choice gives bit-identical results (tests/test_edm_gpu.py runs each case under all of them).
- * waves_per_realisation: 0 = by realisation count (default: a workgroup of four waves per realisation below 600
- * realisations, one wave per realisation from there), 1 or 4 = that form always.  uniform_division: 1 (default) = the
+ * waves_per_realisation: 0 = by realisation count (default: a workgroup of four waves per realisation for 48 up to
+ * one realisation per CU, one wave per realisation otherwise), 1 or 4 = that form always.  uniform_division: 1 (default) = the
  * exact quotient in three or five operations (multiply by the divisor's rounded reciprocal + one or two correction steps;
  * one only where the device has proved it exact for that divisor) where a divisor is the same for the whole launch,
  * 0 = IEEE division everywhere. */

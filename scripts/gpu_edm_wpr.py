@@ -14,7 +14,7 @@ def main():
     Z = [0.3310, 0.6914, 1.3557]
     for n_grid in (1024, 512):
         for sigma in (0.0, 0.3):
-            for R in (1, 16, 64, 256, 1000, 2000, 3000, 4000, 6000, 8000, 16384):
+            for R in (1, 8, 16, 32, 64, 128, 256, 300, 400, 512, 600, 1000, 2000, 4000, 16384):
                 if sigma > 0 and R not in (64, 1000, 4000):
                     continue
                 row, sig = [], None
