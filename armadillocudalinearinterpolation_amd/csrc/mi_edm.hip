@@ -188,7 +188,8 @@ __device__ __forceinline__ void wave_argmin(float& best, unsigned& key)
 
 // ---- EvolveKernel (EventDrivenMap.cu:575-674): one wave64 per realisation ----
 // Neuron state lives in LDS, [wave][array][slot*64 + lane]: every lane only ever touches its own slots, so the event
-// loop needs no barrier and the per-neuron loop stays rolled (63 VGPRs).
+// loop needs no barrier and the per-neuron loop stays rolled (64 VGPRs, held there by amdgpu_waves_per_eu: eight waves per
+// SIMD at N = 512).
 //
 // Dead slices.  A 64-neuron slice whose every neuron starts with a NaN synaptic variable (the stretch that the lift
 // profile poisons through 0 * inf, LiftKernel :505-542 -- neurons 820..1023 at the reference's parameters, i.e. slices
@@ -203,7 +204,8 @@ __device__ __forceinline__ void wave_argmin(float& best, unsigned& key)
 // LDS per workgroup: w[1024] + 4 waves * (2 or 3) arrays * popcount(store)*64 floats + 4 * 64 pending-neuron slots
 // (evolve_lds_bytes).
 // NS: compile-time bound of the per-bump loops (3 = the reference's noSpikes, else kMaxSpikes)
-// UDIV: divisions by the homogeneous model's wave-uniform divisors through edm::div_by's five-operation exact quotient
+// UDIV: divisions by the homogeneous model's wave-uniform divisors through edm::div_by's exact quotient (three or five
+//       operations, see ONE; in the state pass without its range guard when the tracked range of |s| allows it)
 // TAPS: the same computation, also counting into taps[kTap*] how often it reaches the documented decisions
 //       (mi_edm_debug_counters; never what ComputeF launches)
 enum { kTapEvents = 0, kTapMaxEvents, kTapMaxNewton, kTapNewtonCap, kTapEventCap, kTapAccepted, kTapNoFiring, kTapTies, kTapCount };
