@@ -188,8 +188,8 @@ __device__ __forceinline__ void wave_argmin(float& best, unsigned& key)
 
 // ---- EvolveKernel (EventDrivenMap.cu:575-674): one wave64 per realisation ----
 // Neuron state lives in LDS, [wave][array][slot*64 + lane]: every lane only ever touches its own slots, so the event
-// loop needs no barrier and the per-neuron loop stays rolled (64 VGPRs, held there by amdgpu_waves_per_eu: eight waves per
-// SIMD at N = 512).
+// loop needs no barrier and the per-neuron loop stays rolled (64 VGPRs, held there by amdgpu_waves_per_eu for the kernels of up
+// to three bumps: eight waves per SIMD at N = 512; the eight-bump kernels keep their 70-78 registers rather than spill).
 //
 // Dead slices.  A 64-neuron slice whose every neuron starts with a NaN synaptic variable (the stretch that the lift
 // profile poisons through 0 * inf, LiftKernel :505-542 -- neurons 820..1023 at the reference's parameters, i.e. slices
@@ -213,7 +213,7 @@ enum { kTapEvents = 0, kTapMaxEvents, kTapMaxNewton, kTapNewtonCap, kTapEventCap
 // GAP: the host has checked 0 < vth - I <= 1 (edm::gap_settles_sign; UDIV implies it)
 // ONE: the host has proved that ONE correction step makes the quotient by 1 - beta exact (divisor_check_kernel; UDIV only)
 template <int MATH, bool HETERO, int NS, bool UDIV, bool TAPS = false, bool TREE = true, bool GAP = UDIV, bool ONE = false>
-__global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void evolve_kernel(edm::Model M, SpikeSeeds sd, unsigned store,
+__global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS <= 3 ? 8 : 4, 8))) void evolve_kernel(edm::Model M, SpikeSeeds sd, unsigned store,
                                                               unsigned long long* __restrict__ taps,
                                                               const float* __restrict__ v0,
                                                               const float* __restrict__ s0,
