@@ -170,16 +170,22 @@ mi_status mi_group_create(int ndev, const int* devices, mi_group** out)
 mi_status mi_group_destroy(mi_group* g)
 {
     if (!g) return MI_OK;
+    // Every stream of every member drained BEFORE any communicator goes: the chunked gather leaves its broadcasts on the
+    // members' second streams, and a communicator must not be torn down under work that still refers to it.
     for (size_t r = 0; r < g->ctx.size(); ++r) {
         (void)hipSetDevice(g->dev[r]);
         (void)hipStreamSynchronize(g->ctx[r]->stream);
-        if (r < g->red_dev.size() && g->red_dev[r]) (void)hipFree(g->red_dev[r]);
+        if (r < g->gstream.size() && g->gstream[r]) (void)hipStreamSynchronize(g->gstream[r]);
+    }
+    for (size_t r = 0; r < g->ctx.size(); ++r) {
+        (void)hipSetDevice(g->dev[r]);
         if (r < g->comms.size() && g->comms[r] && g->CommDestroy) (void)g->CommDestroy(g->comms[r]);
+    }
+    for (size_t r = 0; r < g->ctx.size(); ++r) {
+        (void)hipSetDevice(g->dev[r]);
+        if (r < g->red_dev.size() && g->red_dev[r]) (void)hipFree(g->red_dev[r]);
         if (g->done[r]) (void)hipEventDestroy(g->done[r]);
-        if (r < g->gstream.size() && g->gstream[r]) {
-            (void)hipStreamSynchronize(g->gstream[r]);
-            (void)hipStreamDestroy(g->gstream[r]);
-        }
+        if (r < g->gstream.size() && g->gstream[r]) (void)hipStreamDestroy(g->gstream[r]);
         if (r < g->gdone.size() && g->gdone[r]) (void)hipEventDestroy(g->gdone[r]);
         if (r < g->cdone.size())
             for (hipEvent_t e : g->cdone[r])
