@@ -37,6 +37,13 @@ constexpr int kEvolveBlock = 256;   // 4 waves = 4 realisations per workgroup
 // kernel fires at ever shorter intervals).  Every wave must reach an exit, so the loop also stops after
 // max_events events (the realisation is then simply not accepted); the oracle applies the same rule.
 constexpr unsigned kMaxEventsLimit = 1u << 24;
+// Evolve's unguarded quotient (evolve_kernel, state_pass) wants |s| < 2^101 throughout.  With beta > 0 every event maps
+// s -> s exp(-beta dt) + beta w with dt >= 0, so |s| grows by at most max |beta w| per event: if the lift profile and the
+// coupling table stay below kBigS = 2^60, |s| < 2^60 (1 + 2^24) < 2^101 after any admissible number of events.  The lift
+// kernel reports the first condition in bit 31 of its live-slice word, the host checks the second, and the launch hands
+// the conjunction to the kernel in bit 31 of `store`.
+constexpr float kBigS = 0x1.0p+60f;
+constexpr unsigned kBigFlag = 0x80000000u, kSliceMask = 0xffffu;
 
 struct SpikeSeeds {
     float U[kMaxSpikes + 1];        // (c, 0, Z1, ..), fp32 (EventDrivenMap.cu:172)
@@ -108,7 +115,7 @@ __device__ __forceinline__ float lift_point(const edm::Model& M, const SpikeSeed
 }
 
 // aux[0] <- bit k set iff the 64-neuron slice k holds a neuron whose synaptic variable is not NaN (the slices Evolve
-// has to carry, see evolve_kernel)
+// has to carry, see evolve_kernel); bit 31 set iff some synaptic variable is infinite or >= 2^60 in magnitude (kBigS)
 template <int MATH>
 __global__ __launch_bounds__(kMaxGrid) void lift_kernel(edm::Model M, SpikeSeeds sd, float* __restrict__ v,
                                                         float* __restrict__ s, unsigned* __restrict__ aux)
@@ -120,6 +127,7 @@ __global__ __launch_bounds__(kMaxGrid) void lift_kernel(edm::Model M, SpikeSeeds
     const unsigned ic = (i < M.N) ? i : M.N - 1u;      // lanes past the grid recompute the last point and store nothing
     const float ss_ = lift_point<MATH>(M, sd, ic, v, s, i < M.N);
     if (__any(i < M.N && ss_ == ss_) && (i & 63u) == 0u) atomicOr(&live, 1u << (i >> 6));
+    if (__any(i < M.N && ss_ == ss_ && !(fabsf(ss_) < kBigS)) && (i & 63u) == 0u) atomicOr(&live, kBigFlag);
     __syncthreads();
     if (i == 0) aux[0] = live;
 }
@@ -188,8 +196,9 @@ __device__ __forceinline__ void wave_argmin(float& best, unsigned& key)
 
 // ---- EvolveKernel (EventDrivenMap.cu:575-674): one wave64 per realisation ----
 // Neuron state lives in LDS, [wave][array][slot*64 + lane]: every lane only ever touches its own slots, so the event
-// loop needs no barrier and the per-neuron loop stays rolled (64 VGPRs, held there by amdgpu_waves_per_eu for the kernels of up
-// to three bumps: eight waves per SIMD at N = 512; the eight-bump kernels keep their 70-78 registers rather than spill).
+// loop needs no barrier and the per-neuron loop stays rolled (64 VGPRs for up to three bumps: eight waves per SIMD at N = 512.
+// amdgpu_waves_per_eu(7, 8) is what gets the scheduler there WITHOUT scratch: left alone it takes 58 registers and a schedule
+// that is 4 % slower at N = 512; asked for (8, 8) it spills two registers to scratch, which no product kernel should need).
 //
 // Dead slices.  A 64-neuron slice whose every neuron starts with a NaN synaptic variable (the stretch that the lift
 // profile poisons through 0 * inf, LiftKernel :505-542 -- neurons 820..1023 at the reference's parameters, i.e. slices
@@ -213,7 +222,7 @@ enum { kTapEvents = 0, kTapMaxEvents, kTapMaxNewton, kTapNewtonCap, kTapEventCap
 // GAP: the host has checked 0 < vth - I <= 1 (edm::gap_settles_sign; UDIV implies it)
 // ONE: the host has proved that ONE correction step makes the quotient by 1 - beta exact (divisor_check_kernel; UDIV only)
 template <int MATH, bool HETERO, int NS, bool UDIV, bool TAPS = false, bool TREE = true, bool GAP = UDIV, bool ONE = false>
-__global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS <= 3 ? 8 : 4, 8))) void evolve_kernel(edm::Model M, SpikeSeeds sd, unsigned store,
+__global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS <= 3 ? 7 : 4, 8))) void evolve_kernel(edm::Model M, SpikeSeeds sd, unsigned store_word,
                                                               unsigned long long* __restrict__ taps,
                                                               const float* __restrict__ v0,
                                                               const float* __restrict__ s0,
@@ -225,6 +234,8 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS
                                                               unsigned* __restrict__ g_accept)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned store = store_word & kSliceMask;            // the live slices
+    const bool s_bounded = (store_word & kBigFlag) != 0u;      // |s| < 2^101 for the whole evolution (see kBigS)
     const unsigned npl = (M.N + 63u) / 64u;
     const unsigned slots = (unsigned)__builtin_popcount(store) * 64u;
     float* w_lds = lds;
@@ -269,8 +280,10 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS
         }
     }
 
-    const unsigned waves_per_grid = gridDim.x * (kEvolveBlock / 64);
-    for (unsigned r = blockIdx.x * (kEvolveBlock / 64) + wave; r < M.R; r += waves_per_grid) {
+    // one realisation per wave: the grid is one workgroup per four realisations (launch_evolve), nothing loops over them here
+    // (and nothing of the set-up above has to survive the event loop)
+    const unsigned r = blockIdx.x * (kEvolveBlock / 64) + wave;
+    if (r < M.R) {
         {
             unsigned a = lane;
             for (unsigned m = store; m != 0u; m &= m - 1u, a += 128u) {
@@ -282,20 +295,20 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS
             }
         }
         // per-bump event slots ([D2]: start at time 0 / index 0); wave-uniform values
-        float lt[NS], ct[NS];
+        unsigned lt[NS], ct[NS];            // (times as bit patterns, so that the slots live in scalar registers like the indices)
         unsigned li[NS], ci[NS];
 #pragma unroll
         for (int m = 0; m < NS; ++m) {
-            lt[m] = 0.0f;
-            ct[m] = 0.0f;
+            lt[m] = 0u;                     // 0.0f
+            ct[m] = 0u;
             ci[m] = 0u;
             li[m] = (m < (int)M.S) ? (unsigned)sd.ind[m] : 0u;
         }
         unsigned crossed = 0;
         float now = 0.0f;
-        // range of |s| over this lane's neurons as the last state pass left it (kTrack; the first pass runs guarded)
+        // smallest |s| over this lane's neurons as the last state pass left it (kTrack; the first pass runs guarded)
         constexpr bool kTrack = UDIV && !HETERO && MATH == 0;
-        float s_lo = 0.0f, s_hi = INFINITY;
+        float s_lo = 0.0f;
         // Candidate bookkeeping.  Every event needs min over neurons of eventTime().  Neurons that will not
         // fire contribute exactly kNever; the few that will (the bump fronts) need a divergent Newton solve.
         // Instead of running that loop once per 64-neuron slice, each lane records its firing neurons in a
@@ -416,7 +429,7 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS
             } else {
                 e1 = edm::expf_<MATH>(-dt);
             }
-            const unsigned lane4 = lane * 4u, idx4 = idx * 4u;
+            const unsigned idx4 = idx * 4u;
             const bool sign_settles = edm::gap_settles_sign<GAP>(M);
             typedef __attribute__((address_space(3))) const float lds_cfloat;
             const unsigned w_base = (unsigned)(uintptr_t)(lds_cfloat*)w_lds;
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS
             // the range is known beforehand (below)
             auto state_pass = [&](auto guard_tag) {
             constexpr bool kGuard = decltype(guard_tag)::value;
-            float lo = INFINITY, hi = 0.0f;
+            float lo = INFINITY;
             unsigned a = lane;
 #pragma unroll 1                                                            // rolled: measured (DESIGN_HISTORY.md section 4)
             for (unsigned m = store; m != 0u; m &= m - 1u, a += 128u) {      // live slices only
@@ -436,7 +449,7 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS
                 // the coupling value w[|i - idx|] (|i - idx| < kMaxGrid: i < npl*64 <= kMaxGrid, idx < N), addressed in bytes:
                 // 4 |i - idx| = |4 i - 4 idx| in one v_sad_u32.  (Every LDS read of the slice before its arithmetic.)
                 unsigned w_at;                                            // LDS address: the table's own goes in as v_sad_u32's addend
-                asm("v_sad_u32 %0, %1, %2, %3" : "=v"(w_at) : "v"((k << 8) | lane4), "s"(idx4), "v"(w_base));
+                asm("v_sad_u32 %0, %1, %2, %3" : "=v"(w_at) : "v"((lane << 2) | (k << 8)), "s"(idx4), "v"(w_base));
                 const float wd = *reinterpret_cast<lds_cfloat*>((uintptr_t)w_at);
                 float vv = V[a] * e1;
                 vv = vv + (M.I * (1.0f - e1) + edm::div_by<MATH, UDIV && !HETERO, kGuard, ONE>(so * e1, 1.0f - bk) * (e2 - 1.0f));
@@ -451,10 +464,7 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS
                 sn = sn + (HETERO ? bk * wd : wd);
                 V[a] = vv;
                 S[a] = sn;
-                if constexpr (kTrack) {          // range of |s| over the lane's neurons (a NaN leaves both bounds alone)
-                    asm("v_min_f32 %0, |%1|, %0" : "+v"(lo) : "v"(sn));
-                    asm("v_max_f32 %0, |%1|, %0" : "+v"(hi) : "v"(sn));
-                }
+                if constexpr (kTrack) asm("v_min_f32 %0, |%1|, %0" : "+v"(lo) : "v"(sn));   // (a NaN leaves the bound alone)
                 // With 0 < vth - I <= 1 no lane of the slice can fire unless some s is >= 0 (will_fire's first exit): most slices
                 // of most events leave here with one scalar branch -- inside will_fire the same exit costs an exec-mask save /
                 // restore and the two instructions that fold an all-false result into pend.
@@ -462,14 +472,14 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS
                 pend |= (edm::will_fire<MATH, UDIV && !HETERO, (MI_EDM_FIRE_FILTER != 0), GAP>(M, vv, sn, bk) ? 1u : 0u) << pos_of(k);   // (padding lanes: masked below)
             }
             s_lo = lo;
-            s_hi = hi;
             };
             if constexpr (kTrack) {
                 // The exact quotient (so * e1) / (1 - beta) needs |so * e1| in [2^-100, 2^101) (or a NaN); its own test of that is
-                // two compares and a scalar branch in every slice.  The previous pass left the range of |s| over this lane's
-                // neurons: |so * e1| <= |so| < 2^101, and RN(s_lo * e1) >= 2^-99 puts every |so * e1| above 2^-100 -- then the
-                // whole pass runs without the per-slice test.  (First event, zeros, subnormals, infinities: the guarded pass.)
-                const bool known = s_hi < 0x1.0p+101f && s_lo * e1 >= 0x1.0p-99f;
+                // two compares and a scalar branch in every slice.  Above: |so * e1| <= |so| < 2^101 for the whole evolution when
+                // the launch says so (s_bounded, see kBigS).  Below: the previous pass left the smallest |s| over this lane's
+                // neurons, and RN(s_lo * e1) >= 2^-99 puts every |so * e1| above 2^-100 -- then the whole pass runs without the
+                // per-slice test.  (First event, zeros, subnormals, a 100-unit "no neuron fires" step: the guarded pass.)
+                const bool known = s_bounded && s_lo * e1 >= 0x1.0p-99f;
                 if (__any(!known)) state_pass(std::true_type{});
                 else state_pass(std::false_type{});
             } else {
@@ -493,11 +503,12 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS
             }
             if (!(crossed & (1u << mi))) {
                 const bool after = now > M.T;
+                const unsigned now_b = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(now));   // (wave-uniform)
 #pragma unroll
                 for (int m = 0; m < NS; ++m) {
                     if (mi == (unsigned)m) {
-                        if (after) { ct[m] = now; ci[m] = idx; }
-                        else { lt[m] = now; li[m] = idx; }
+                        if (after) { ct[m] = now_b; ci[m] = idx; }
+                        else { lt[m] = now_b; li[m] = idx; }
                     }
                 }
                 if (after) crossed += (1u << mi);
@@ -508,9 +519,9 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS
         for (int m = 0; m < NS; ++m) {
             if (lane == (unsigned)m && m < (int)M.S) {
                 const size_t k = (size_t)m * M.R + r;
-                g_t0[k] = lt[m];
+                g_t0[k] = __uint_as_float(lt[m]);
                 g_i0[k] = (unsigned short)li[m];
-                g_t1[k] = ct[m];
+                g_t1[k] = __uint_as_float(ct[m]);
                 g_i1[k] = (unsigned short)ci[m];
             }
         }
@@ -829,6 +840,7 @@ struct mi_edm {
     bool no_uniform_div = false;       // never take the exact quotient by wave-uniform divisors
     // one-step quotient (edm::div_by ONE): the divisor 1 - beta it was last proved (or refuted) for; NaN = none yet
     float checked_divisor = NAN;
+    float w_abs_max = INFINITY;        // max |w| of the coupling table on the device (NaN / inf entries: inf)
     bool one_step_exact = false;
 };
 
@@ -979,12 +991,16 @@ mi_status one_step_quotient_exact(mi_edm* e, float c, bool* exact)
 
 // live: the lift kernel's live-slice mask (wave-per-realisation form only; ignored by the latency form)
 template <int MATH>
-mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live)
+mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live_word)
 {
+    // the lift kernel's word: live slices + "some |s| is infinite or >= 2^60"; what goes to the kernel in the flag's place is
+    // "|s| stays below 2^101 for the whole evolution" (kBigS): a bounded lift profile, beta > 0 and a bounded coupling table
+    const bool s_bounded = (live_word & kBigFlag) == 0u && e->p.beta_mean > 0.0f && e->p.beta_mean * e->w_abs_max < 0.5f * kBigS;
+    const unsigned live = (live_word & kSliceMask) | (s_bounded ? kBigFlag : 0u);
     mi_ctx* ctx = e->ctx;
     const unsigned N = e->p.n_grid, R = e->p.n_real;
     const bool hetero = e->p.beta_stddev != 0.0f;
-    const size_t lds_bytes = evolve_lds_bytes(hetero, live);
+    const size_t lds_bytes = evolve_lds_bytes(hetero, live & kSliceMask);
     // One workgroup per four realisations, however many that is: the hardware's workgroup dispatcher then IS the work
     // queue (a finished workgroup's slot goes to the next four realisations; per-workgroup set-up is the 4 KiB coupling
     // table, microseconds against milliseconds per realisation), so the launch ends within one realisation's time of the
@@ -1079,6 +1095,9 @@ mi_status run_pipeline(mi_edm* e, const SpikeSeeds& sd)
     if (!e->w_valid) {
         std::vector<float> w(e->p.n_grid);
         build_coupling<MATH>(e->p, w.data());
+        float wmax = 0.0f;
+        for (float x : w) wmax = (fabsf(x) <= wmax) ? wmax : fabsf(x);      // (a NaN entry ends up as the maximum)
+        e->w_abs_max = (wmax == wmax) ? wmax : INFINITY;
         MI_HIP(ctx, hipMemcpyAsync(e->d_w, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
         MI_HIP(ctx, hipStreamSynchronize(ctx->stream));   // w is a stack-lifetime host buffer
         e->w_valid = true;
@@ -1351,6 +1370,7 @@ mi_status mi_edm_debug_counters(mi_edm* e, uint64_t out[MI_EDM_N_COUNTERS])
     if (err == hipSuccess) err = hipMemcpyAsync(&live, e->d_aux, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
     if (err == hipSuccess) {
+        live &= kSliceMask;
         const bool hetero = e->p.beta_stddev != 0.0f, three = e->p.n_spikes <= 3;
         const size_t lds_bytes = evolve_lds_bytes(hetero, live);
         const unsigned blocks = (e->p.n_real + 3) / 4;

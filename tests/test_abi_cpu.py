@@ -107,3 +107,32 @@ def test_shard_bounds_host_arithmetic():
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             sizes = [h - l for l, h in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_no_product_kernel_uses_scratch(tmp_path):
+    """Every gfx950 kernel of libmi355interp.so runs out of registers and LDS alone: `.private_segment_fixed_size` is 0 in
+    the code objects' metadata.  (A register spill would be a performance bug, and scratch brings the runtime's dynamic
+    scratch management into a process that otherwise never needs it.)  Read with the LLVM tools that ship with ROCm."""
+    import glob
+    import re
+    import shutil
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(os.path.join(llvm, "llvm-objdump")) and os.path.exists(os.path.join(llvm, "llvm-readelf"))):
+        pytest.skip("ROCm's llvm-objdump / llvm-readelf not found")
+    from armadillocudalinearinterpolation_amd import _build
+    _build.build_lib()
+    work = tmp_path / "co"
+    work.mkdir()
+    shutil.copy(_build.LIB_PATH, work / "lib.so")                       # (--offloading writes the bundles next to its input)
+    out = subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", "lib.so"], cwd=work, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    bundles = glob.glob(str(work / "lib.so.*gfx950"))
+    assert bundles, "no gfx950 code object in the library"
+    kernels = 0
+    for b in bundles:
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", b], capture_output=True, text=True).stdout
+        sizes = re.findall(r"\.private_segment_fixed_size:\s*(\d+)", notes)
+        names = re.findall(r"\.name:\s*(\S+)", notes)
+        kernels += len(sizes)
+        assert all(int(x) == 0 for x in sizes), [n for n in names if "evolve" in n or "interp" in n][:3]
+    assert kernels >= 50          # (the evolve, interp1, interp2, restrict and probe kernels)
