@@ -342,6 +342,7 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS
             unsigned bkey = base_key;         // (~0 with best = +inf: wave_argmin reads key + 1 = 0 as "no candidate")
             // Firing-time solves, one round = the lowest pending neuron of every lane.  Which lane solves a neuron does not
             // matter: the minimum below is lexicographic in (time, tie key).
+            __builtin_amdgcn_s_setprio(0);
             if constexpr (MATH == 0) {
             // EXACT math: the round's neurons are compacted into `list` (rank by v_mbcnt over the ballot) and each goes to a
             // lane PAIR (j, j + 32) that shares the two software exponentials and the two IEEE divisions of a Newton
@@ -407,6 +408,11 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS
                 if (bb >= edm::kNever) tap_quiet += 1u;
                 else if (__builtin_popcountll(__ballot(mine == bb)) > 1) tap_ties += 1u;   // ... or of two lanes
             }
+            // From here to the next Newton rounds the wave runs at raised priority: the arg-min (two dependent DPP chains), the
+            // exponentials and the state pass are what the other waves of the SIMD wait behind when they meet a wave that is in
+            // its -- long, few-lane -- Newton rounds (priority 0): -2.3 % at N = 1024, -0.7 % at N = 512 (gpurun_out/r04_ab27.log;
+            // raising it for the state pass alone does nothing).
+            __builtin_amdgcn_s_setprio(2);
             wave_argmin(best, bkey);
             // the winner is the same in every lane: in scalar registers the event bookkeeping below (nearest bump,
             // crossed mask) runs on the scalar unit
