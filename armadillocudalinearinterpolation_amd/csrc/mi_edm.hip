@@ -410,7 +410,7 @@ __global__ __launch_bounds__(kEvolveBlock) __attribute__((amdgpu_waves_per_eu(NS
             }
             // From here to the next Newton rounds the wave runs at raised priority: the arg-min (two dependent DPP chains), the
             // exponentials and the state pass are what the other waves of the SIMD wait behind when they meet a wave that is in
-            // its -- long, few-lane -- Newton rounds (priority 0): -2.3 % at N = 1024, -0.7 % at N = 512 (gpurun_out/r04_ab27.log;
+            // its -- long, few-lane -- Newton rounds (priority 0): -2.3 % at N = 1024, -0.7 % at N = 512 (profiles/r04_ab_runs.log, block r04_ab27;
             // raising it for the state pass alone does nothing).
             __builtin_amdgcn_s_setprio(2);
             wave_argmin(best, bkey);
@@ -1052,7 +1052,7 @@ mi_status launch_evolve(mi_edm* e, const SpikeSeeds& sd, unsigned live_word)
         else MI_EVOLVE_G(H, NS, UD, true, false);                                                                 \
     } while (0)
         // The exact quotient by uniform divisors (edm::div_by): at every realisation count since the state pass runs it without
-        // its guard (range tracking) -- R = 600 .. 3000: -4 .. -10 %, beyond: the kernel it always took (gpurun_out/r04_ab20.log).
+        // its guard (range tracking) -- R = 600 .. 3000: -4 .. -10 %, beyond: the kernel it always took (profiles/r04_ab_runs.log, block r04_ab20).
         // (Rounds 2-3 took it only from three waves per SIMD: with its guard it was slower on an underfilled device.)
         // edm::div_by<.., true> relies on its divisors -- 1 - beta, beta - 1 and vth - I -- lying in [2^-20, 2^20] in magnitude.
         auto in_range = [](float c) { return fabsf(c) >= 0x1.0p-20f && fabsf(c) <= 0x1.0p+20f; };
